@@ -1,0 +1,596 @@
+// gnsscorr_acq.hip -- parallel code phase acquisition for gfx950 (MI355X).
+//
+// Replaces sdracquisition()'s loop (ref src/sdracq.c:29-43): per iteration
+// pcorrelator() (ref src/sdrcmn.c:738-773) = mixcarr + cpxcpx + cpxconv per
+// Doppler bin, accumulated into P, then checkacquisition() (ref
+// src/sdracq.c:71-95).
+//
+// The reference's FFT length m = 2*nsamp (32736) is replaced by L = 32768:
+// the replica has only nsamp non-zero samples and the data window 2*nsamp, so
+// lags 0..nsamp-1 never wrap for any L >= 2*nsamp-1 and the correlation values
+// are the same numbers (hard part 3).  A length-32768 transform is
+// done as two LDS-resident 16384-point transforms (gnsscorr_fft.h):
+//
+//   acq_fwd  (per Doppler bin, iteration; shared by all SVs of a grid):
+//            carrier wipe-off of the 2*nsamp window straight from the HBM
+//            ring, FFT of the even and of the odd samples, radix-2 combine,
+//            spectrum stored split by parity of the frequency index.
+//   acq_code (per channel, once): same for the zero-padded +-1 replica.
+//   acq_corr (per channel x Doppler bin): for every iteration, X*conj(C) on
+//            load, inverse FFT of the even-index and odd-index halves,
+//            y[k] = E[k] + w^-k O[k], |y|^2/L^2 added to fp64 accumulators that
+//            live in registers across the iterations; after each iteration
+//            the row statistics checkacquisition() needs are reduced in the
+//            workgroup.  P only leaves the chip when the caller asks for it.
+//   acq_final (per channel): the decision of checkacquisition() after each
+//            iteration, first success wins (ref src/sdracq.c:39-42).
+#include <vector>
+
+#include "gnsscorr_ctx.h"
+#include "gnsscorr_fft.h"
+
+#define GC_L        32768
+#define GC_LH       16384
+
+using gcfft::cadd;
+using gcfft::cmul;
+using gcfft::cmulc;
+using gcfft::csub;
+
+struct GcAcqWork {
+    float2 *tw16k = nullptr;    // exp(-2 pi i t/16384), t < 16384
+    float2 *tw32k = nullptr;    // exp(-2 pi i t/32768), t < 16384
+    float2 *X = nullptr;        // [grid][iter][bin][2][16384]
+    size_t  X_elems = 0;
+    float2 *C = nullptr;        // [ch][2][16384]
+    GcAcqRow *rows = nullptr;   // [ch][iter][bin]
+    int *iters = nullptr;       // [ch] iteration limit for acq_corr
+    gnsscorr_acqres_t *res = nullptr;   // [ch]
+    float2 *Es = nullptr;       // acq_corr scratch: [ch][bin][16384]
+    double *P = nullptr;        // one channel's power array (on demand)
+    size_t P_elems = 0;
+    int ngrid = 0, maxfreq = 0, maxintg = 0;
+    std::vector<int> grid_chan;         // a representative channel per grid
+    int *d_grid_chan = nullptr;         // device copy of grid_chan
+    uint64_t *d_grid_wrpos = nullptr;   // ring write position seen by each grid
+    bool code_ready = false;
+    uint64_t last_wrpos[2] = {0, 0};
+    bool ran = false;
+};
+
+namespace {
+
+// carrier LUT (ref src/sdrcmn.c:643-648)
+__constant__ signed char aCos32[32] = {32, 31, 30, 27, 23, 18, 12, 6, 0, -6, -12, -18, -23, -27, -30, -31,
+                                       -32, -31, -30, -27, -23, -18, -12, -6, 0, 6, 12, 18, 23, 27, 30, 31};
+__constant__ signed char aSin32[32] = {0, 6, 12, 18, 23, 27, 30, 31, 32, 31, 30, 27, 23, 18, 12, 6,
+                                       0, -6, -12, -18, -23, -27, -30, -31, -32, -31, -30, -27, -23, -18, -12, -6};
+
+__global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= GC_LH) return;
+    double s, c;
+    sincospi(-2.0 * (double)t / 16384.0, &s, &c);
+    tw16k[t] = make_float2((float)c, (float)s);
+    sincospi(-2.0 * (double)t / 32768.0, &s, &c);
+    tw32k[t] = make_float2((float)c, (float)s);
+}
+
+// Forward 32768-point transform of a sequence given by a per-sample functor,
+// result written split by parity: out[p][q] = X[2q + p].
+template <class F>
+__device__ __forceinline__ void fwd32k_store(F sample, float2 *lds, const float2 *__restrict__ tw16k,
+                                             const float2 *__restrict__ tw32k, float2 *__restrict__ out,
+                                             int tid)
+{
+    float2 v[32], e[32];
+    // even samples: input index j <-> sample 2j
+    gcfft::fft16k<-1>([&](int j) { return sample(2 * j); }, v, lds, tw16k, tid);
+#pragma unroll
+    for (int s = 0; s < 32; s++) e[s] = v[s];
+    __syncthreads();
+    gcfft::fft16k<-1>([&](int j) { return sample(2 * j + 1); }, v, lds, tw16k, tid);
+    // X[f] = E[f] + w^f O[f], X[f + 16384] = E[f] - w^f O[f], w = exp(-2 pi i/32768)
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+        const int f = tid + 512 * s;
+        const float2 t = cmul(v[s], tw32k[f]);
+        const float2 lo = cadd(e[s], t), hi = csub(e[s], t);
+        float2 *o = out + (size_t)(f & 1) * GC_LH + (f >> 1);
+        o[0] = lo;
+        o[GC_LH / 2] = hi;          // (f + 16384) >> 1 = (f >> 1) + 8192, same parity
+    }
+}
+
+// acq_fwd: grid (bin, iteration, grid group)
+__global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
+    const GcChan *__restrict__ chan, const int *__restrict__ grid_chan, const double *__restrict__ freqs,
+    const uint64_t *__restrict__ grid_wrpos, const float2 *__restrict__ tw16k,
+    const float2 *__restrict__ tw32k, float2 *__restrict__ X, int maxfreq, int maxintg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int bin = blockIdx.x, it = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+    const GcChan &c = chan[grid_chan[g]];
+    if (bin >= c.nfreq || it >= c.intg) return;
+    const int n = c.nsamp, n2 = 2 * n, dtype = c.dtype;
+    // window of iteration `it`: ref src/sdracq.c:24-32
+    const uint64_t buffloc = grid_wrpos[g] - (uint64_t)(c.intg + 1) * n + (uint64_t)it * n;
+    const uint64_t base = buffloc % c.ringlen;
+    const int8_t *ring = c.ring;
+    const uint64_t ringlen = c.ringlen;
+    const double ps = __dmul_rn(__dmul_rn(freqs[c.freq_off + bin], (double)GC_CDIV), c.ti);
+    const float sc = (float)((1.0 / 32.0) / (double)c.nfft);     // CSCALE/m, ref src/sdrcmn.c:764
+
+    auto sample = [&](int s) -> float2 {
+        if (s >= n2) return make_float2(0.f, 0.f);
+        uint64_t pos = base + (uint64_t)s;
+        if (pos >= ringlen) pos -= ringlen;
+        const int idx = ((int)__dmul_rn((double)s, ps)) & (GC_CDIV - 1);   // phase starts at 0 (:761)
+        const int cs_ = aCos32[idx], sn_ = aSin32[idx];
+        int I, Q;
+        if (dtype == 2) {
+            const int d0 = ring[2 * pos], d1 = ring[2 * pos + 1];
+            I = cs_ * d0 - sn_ * d1;
+            Q = sn_ * d0 + cs_ * d1;
+        } else {
+            const int d0 = ring[pos];
+            I = cs_ * d0;
+            Q = sn_ * d0;
+        }
+        return make_float2((float)I * sc, (float)Q * sc);
+    };
+    float2 *out = X + (((size_t)g * maxintg + it) * maxfreq + bin) * GC_L;
+    fwd32k_store(sample, lds, tw16k, tw32k, out, tid);
+}
+
+// acq_code: grid (channel)
+__global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *__restrict__ chan,
+                                                                  const float2 *__restrict__ tw16k,
+                                                                  const float2 *__restrict__ tw32k,
+                                                                  float2 *__restrict__ C)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const GcChan &c = chan[ch];
+    const int n = c.nsamp, clen = c.clen;
+    const double ci = __dmul_rn(c.ti, c.crate);      // sdr->ci, ref src/sdrinit.c:605
+    const int8_t *code = c.code;
+    // rescode(code, clen, 0, 0, ci, nsamp) zero-padded (ref src/sdrinit.c:650-651)
+    auto sample = [&](int s) -> float2 {
+        if (s >= n) return make_float2(0.f, 0.f);
+        long long t = (long long)__dmul_rn((double)s, ci);
+        while (t >= clen) t -= clen;
+        return make_float2((float)code[(int)t], 0.f);
+    };
+    fwd32k_store(sample, lds, tw16k, tw32k, C + (size_t)ch * GC_L, tid);
+}
+
+// ---- workgroup reductions used by acq_corr --------------------------------
+struct MaxIdx { double v; int k; };
+
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b)
+{   // larger value wins, first index on ties (maxvd's strict '<', ref src/sdrcmn.c:461-476)
+    return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a;
+}
+
+__device__ __forceinline__ MaxIdx wg_argmax(MaxIdx m, double *sd, int *si, int tid)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MaxIdx t;
+        t.v = __shfl_xor(m.v, o, 64);
+        t.k = __shfl_xor(m.k, o, 64);
+        m = better(m, t);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { sd[tid >> 6] = m.v; si[tid >> 6] = m.k; }
+    __syncthreads();
+    MaxIdx r; r.v = sd[0]; r.k = si[0];
+#pragma unroll
+    for (int w = 1; w < GC_FFT_THREADS / 64; w++) { MaxIdx t; t.v = sd[w]; t.k = si[w]; r = better(r, t); }
+    return r;
+}
+
+__device__ __forceinline__ void wg_sum_max(double &s, double &m, double *sd, int tid)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        m = fmax(m, __shfl_xor(m, o, 64));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { sd[tid >> 6] = s; sd[8 + (tid >> 6)] = m; }
+    __syncthreads();
+    s = sd[0]; m = sd[8];
+#pragma unroll
+    for (int w = 1; w < GC_FFT_THREADS / 64; w++) { s += sd[w]; m = fmax(m, sd[8 + w]); }
+}
+
+// acq_corr: grid (bin, channel)
+__global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
+    const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32k,
+    const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
+    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg,
+    float2 *__restrict__ Escratch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    // E[] of the current iteration waits here (L2-resident, 128 KiB per workgroup) while the
+    // second transform owns the registers
+    float2 *Es = Escratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GC_LH;
+    double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 16 doubles
+    int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 128);       // 8 ints
+    const int bin = blockIdx.x, tid0 = threadIdx.x;
+    const int ch = Pout ? pout_ch : blockIdx.y;
+    const GcChan &c = chan[ch];
+    if (bin >= c.nfreq) return;
+    const int n = c.nsamp, nit = iters[ch], nsc2 = 2 * c.nsampchip;
+    const float2 *Cc = C + (size_t)ch * GC_L;
+    const float invL2 = 1.0f / ((float)GC_L * (float)GC_L);
+
+    double P[32];
+#pragma unroll
+    for (int s = 0; s < 32; s++) P[s] = 0.0;
+
+    for (int it = 0; it < nit; it++) {
+        // Opaque copy of the lane id: keeps the ~200 address computations of one iteration from
+        // being hoisted out of the loop (they would be spilled to scratch, not kept in VGPRs).
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const float2 *Xb = X + (((size_t)c.grid * maxintg + it) * maxfreq + bin) * GC_L;
+        float2 v[32];
+        // E = IFFT16k(Y[2q]), O = IFFT16k(Y[2q+1]) with Y = X conj(C) (ref src/sdrcmn.c:236-240;
+        // the reference's extra minus sign vanishes under |.|^2)
+        gcfft::fft16k<+1>([&](int q) { return cmulc(Xb[q], Cc[q]); }, v, lds, tw16k, tid);
+#pragma unroll
+        for (int s = 0; s < 32; s++) Es[tid + 512 * s] = v[s];     // same lane reads it back below
+        __syncthreads();
+        gcfft::fft16k<+1>([&](int q) { return cmulc(Xb[GC_LH + q], Cc[GC_LH + q]); }, v, lds, tw16k, tid);
+        // y[k] = E[k] + conj(w^k) O[k]; P[k] += |y|^2 / L^2 (ref src/sdrcmn.c:244-246 with the
+        // reference's m-point scaling folded: (m/L)^2/m^2 = 1/L^2)
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int k = tid + 512 * s;
+            const float2 y = cadd(Es[k], cmulc(v[s], tw32k[k]));
+            const float pw = fmaf(y.x, y.x, y.y * y.y) * invL2;
+            P[s] += (double)pw;
+        }
+
+        // row statistics for checkacquisition()
+        MaxIdx m; m.v = -1.0; m.k = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int k = tid + 512 * s;
+            if (k < n) { MaxIdx t; t.v = P[s]; t.k = k; m = better(m, t); }
+        }
+        m = wg_argmax(m, sd, si, tid);
+        int exs = m.k - nsc2; if (exs < 0) exs += n;
+        int exe = m.k + nsc2; if (exe >= n) exe -= n;
+        double so = 0.0, mo = -1.0;
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int k = tid + 512 * s;
+            if (k < n) {
+                const bool outside = (exs <= exe) ? (k < exs || k > exe) : (k < exs && k > exe);
+                if (outside) so += P[s];
+                if (outside || k == 0) mo = fmax(mo, P[s]);    // element 0 seeds maxvd()
+            }
+        }
+        wg_sum_max(so, mo, sd, tid);
+        if (tid == 0) {
+            GcAcqRow r;
+            r.rowmax = m.v; r.sum_out = so; r.max_out = mo; r.argmax = m.k; r.pad = 0;
+            rows[((size_t)ch * maxintg + it) * maxfreq + bin] = r;
+        }
+        __syncthreads();      // LDS image and reduction scratch are reused next iteration
+    }
+    if (Pout) {
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int k = tid0 + 512 * s;
+            if (k < n) Pout[(size_t)bin * n + k] = P[s];
+        }
+    }
+}
+
+// acq_final: one lane per channel walks iterations and bins
+__global__ void acq_final_kernel(const GcChan *__restrict__ chan, const double *__restrict__ freqs,
+                                 const GcAcqRow *__restrict__ rows, const uint64_t *__restrict__ grid_wrpos,
+                                 gnsscorr_acqres_t *__restrict__ res, int *__restrict__ iters_out, int nch,
+                                 int maxfreq, int maxintg)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    const GcChan &c = chan[ch];
+    const int n = c.nsamp;
+    gnsscorr_acqres_t r;
+    r.acqcodei = 0; r.freqi = 0; r.acqfreq = 0; r.cn0 = 0; r.peakr = 0; r.flagacq = 0; r.iters = c.intg;
+    const uint64_t b0 = grid_wrpos[c.grid] - (uint64_t)(c.intg + 1) * n;
+    int it = 0;
+    for (; it < c.intg; it++) {
+        const GcAcqRow *row = rows + ((size_t)ch * maxintg + it) * maxfreq;
+        int fi = 0;
+        for (int b = 1; b < c.nfreq; b++)
+            if (row[b].rowmax > row[fi].rowmax) fi = b;         // lowest flat index wins ties
+        const GcAcqRow w = row[fi];
+        const int ne = 4 * c.nsampchip + 1;                     // samples inside the excluded window
+        const double meanP = w.sum_out / (double)(n - ne);
+        r.cn0 = 10.0 * log10(w.rowmax / meanP / c.ctime);
+        r.peakr = w.rowmax / w.max_out;
+        r.acqcodei = w.argmax;
+        r.freqi = fi;
+        r.acqfreq = freqs[c.freq_off + fi];
+        if (r.peakr > 3.0) { r.flagacq = 1; break; }            // ACQTH, ref src/sdr.h:148
+    }
+    r.iters = r.flagacq ? it + 1 : c.intg;
+    // ref src/sdracq.c:51-53 / :62
+    r.buffloc = r.flagacq ? b0 + (uint64_t)r.acqcodei : b0 + (uint64_t)c.intg * n;
+    res[ch] = r;
+    if (iters_out) iters_out[ch] = r.iters;
+}
+
+__global__ void fill_int_kernel(int *p, const GcChan *__restrict__ chan, int nch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nch) p[i] = chan[i].intg;
+}
+
+// stand-alone batch FFT (op-level entry point and tests): grid (batch)
+template <int S>
+__global__ __launch_bounds__(GC_FFT_THREADS) void fft16k_kernel(const float2 *__restrict__ in,
+                                                                float2 *__restrict__ out,
+                                                                const float2 *__restrict__ tw16k)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const float2 *x = in + (size_t)blockIdx.x * GC_LH;
+    float2 *y = out + (size_t)blockIdx.x * GC_LH;
+    float2 v[32];
+    gcfft::fft16k<S>([&](int j) { return x[j]; }, v, lds, tw16k, tid);
+#pragma unroll
+    for (int s = 0; s < 32; s++) y[tid + 512 * s] = v[s];
+}
+
+// power spectrum of a 16384- or 32768-point sequence (cpxpspec, ref src/sdrcmn.c:261-276)
+__global__ __launch_bounds__(GC_FFT_THREADS) void pspec_kernel(const float2 *__restrict__ in, int n,
+                                                               const float2 *__restrict__ tw16k,
+                                                               const float2 *__restrict__ tw32k,
+                                                               double *__restrict__ pspec, int flagsum)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    float2 v[32];
+    if (n == GC_LH) {
+        gcfft::fft16k<-1>([&](int j) { return in[j]; }, v, lds, tw16k, tid);
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int f = tid + 512 * s;
+            const double p = (double)fmaf(v[s].x, v[s].x, v[s].y * v[s].y);
+            pspec[f] = flagsum ? pspec[f] + p : p;
+        }
+    } else {
+        float2 e[32];
+        gcfft::fft16k<-1>([&](int j) { return in[2 * j]; }, v, lds, tw16k, tid);
+#pragma unroll
+        for (int s = 0; s < 32; s++) e[s] = v[s];
+        __syncthreads();
+        gcfft::fft16k<-1>([&](int j) { return in[2 * j + 1]; }, v, lds, tw16k, tid);
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int f = tid + 512 * s;
+            const float2 t = cmul(v[s], tw32k[f]);
+            const float2 lo = cadd(e[s], t), hi = csub(e[s], t);
+            const double pl = (double)fmaf(lo.x, lo.x, lo.y * lo.y), ph = (double)fmaf(hi.x, hi.x, hi.y * hi.y);
+            pspec[f] = flagsum ? pspec[f] + pl : pl;
+            pspec[f + GC_LH] = flagsum ? pspec[f + GC_LH] + ph : ph;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void gc_acq_free(gnsscorr_ctx *ctx)
+{
+    GcAcqWork *w = ctx->acq;
+    if (!w) return;
+    hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
+    hipFree(w->iters); hipFree(w->res); hipFree(w->P); hipFree(w->Es);
+    hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos);
+    delete w;
+    ctx->acq = nullptr;
+}
+
+static int acq_tables(gnsscorr_ctx *ctx)
+{
+    if (!ctx->acq) ctx->acq = new GcAcqWork();
+    GcAcqWork *w = ctx->acq;
+    if (w->tw16k) return GNSSCORR_OK;
+    GC_HIP(hipMalloc((void **)&w->tw16k, sizeof(float2) * GC_LH));
+    GC_HIP(hipMalloc((void **)&w->tw32k, sizeof(float2) * GC_LH));
+    hipLaunchKernelGGL(tw_init_kernel, dim3(GC_LH / 256), dim3(256), 0, ctx->stream, w->tw16k, w->tw32k);
+    GC_HIP(hipGetLastError());
+    {
+        const int lds = GC_FFT_LDS + 256;
+        GC_HIP(hipFuncSetAttribute((const void *)acq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_code_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<+1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)pspec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    return GNSSCORR_OK;
+}
+
+static int acq_prepare(gnsscorr_ctx *ctx)
+{
+    int rc = acq_tables(ctx);
+    if (rc) return rc;
+    GcAcqWork *w = ctx->acq;
+    if (w->C) return GNSSCORR_OK;
+    const int nch = ctx->nch;
+    w->ngrid = 0; w->maxfreq = 0; w->maxintg = 0;
+    w->grid_chan.clear();
+    for (int i = 0; i < nch; i++) {
+        const GcChan &c = ctx->hchan[i];
+        if (c.nsamp > GC_LH || 2 * c.nsamp > GC_L)
+            return gc_fail(GNSSCORR_EINVAL, "acquisition: nsamp %d needs an FFT longer than 32768", c.nsamp);
+        if (c.grid >= w->ngrid) { w->ngrid = c.grid + 1; w->grid_chan.push_back(i); }
+        if (c.nfreq > w->maxfreq) w->maxfreq = c.nfreq;
+        if (c.intg > w->maxintg) w->maxintg = c.intg;
+    }
+    w->X_elems = (size_t)w->ngrid * w->maxintg * w->maxfreq * GC_L;
+    GC_HIP(hipMalloc((void **)&w->X, sizeof(float2) * w->X_elems));
+    GC_HIP(hipMalloc((void **)&w->C, sizeof(float2) * (size_t)nch * GC_L));
+    GC_HIP(hipMalloc((void **)&w->rows, sizeof(GcAcqRow) * (size_t)nch * w->maxintg * w->maxfreq));
+    GC_HIP(hipMalloc((void **)&w->Es, sizeof(float2) * (size_t)nch * w->maxfreq * GC_LH));
+    GC_HIP(hipMalloc((void **)&w->iters, sizeof(int) * nch));
+    GC_HIP(hipMalloc((void **)&w->res, sizeof(gnsscorr_acqres_t) * nch));
+    GC_HIP(hipMalloc((void **)&w->d_grid_chan, sizeof(int) * w->ngrid));
+    GC_HIP(hipMalloc((void **)&w->d_grid_wrpos, sizeof(uint64_t) * w->ngrid));
+    GC_HIP(hipMemcpyAsync(w->d_grid_chan, w->grid_chan.data(), sizeof(int) * w->ngrid, hipMemcpyHostToDevice,
+                          ctx->stream));
+    {
+        GcTimed t(ctx, "acq_code");
+        hipLaunchKernelGGL(acq_code_kernel, dim3(nch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
+                           ctx->dchan, w->tw16k, w->tw32k, w->C);
+    }
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
+{
+    if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
+    if (!ctx->nch) return gc_fail(GNSSCORR_ESTATE, "acq_run: no channels set");
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = acq_prepare(ctx);
+    if (rc) return rc;
+    GcAcqWork *w = ctx->acq;
+    std::vector<uint64_t> gw(w->ngrid);
+    for (int g = 0; g < w->ngrid; g++) {
+        const GcChan &c = ctx->hchan[w->grid_chan[g]];
+        const int ft = ctx->hdesc[w->grid_chan[g]].ftype;
+        const uint64_t wp = wrpos ? wrpos : ctx->ring[ft - 1].wrpos;
+        if (wp < (uint64_t)(c.intg + 1) * c.nsamp)
+            return gc_fail(GNSSCORR_ESTATE, "acq_run: ring %d holds %llu samples, %llu needed", ft,
+                           (unsigned long long)wp, (unsigned long long)((uint64_t)(c.intg + 1) * c.nsamp));
+        gw[g] = wp;
+    }
+    // pageable source: the copy is staged before the call returns
+    GC_HIP(hipMemcpyAsync(w->d_grid_wrpos, gw.data(), sizeof(uint64_t) * w->ngrid, hipMemcpyHostToDevice,
+                          ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    const int lds = GC_FFT_LDS + 256;
+    {
+        GcTimed t(ctx, "acq_fwd");
+        hipLaunchKernelGGL(acq_fwd_kernel, dim3(w->maxfreq, w->maxintg, w->ngrid), dim3(GC_FFT_THREADS), lds,
+                           ctx->stream, ctx->dchan, w->d_grid_chan, ctx->dfreqs, w->d_grid_wrpos, w->tw16k, w->tw32k,
+                           w->X, w->maxfreq, w->maxintg);
+    }
+    GC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fill_int_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, w->iters,
+                       ctx->dchan, ctx->nch);
+    {
+        GcTimed t(ctx, "acq_corr");
+        hipLaunchKernelGGL(acq_corr_kernel, dim3(w->maxfreq, ctx->nch), dim3(GC_FFT_THREADS), lds, ctx->stream,
+                           ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, (double *)nullptr, 0,
+                           w->maxfreq, w->maxintg, w->Es);
+    }
+    GC_HIP(hipGetLastError());
+    {
+        GcTimed t(ctx, "acq_final");
+        hipLaunchKernelGGL(acq_final_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->dchan,
+                           ctx->dfreqs, w->rows, w->d_grid_wrpos, w->res, w->iters, ctx->nch, w->maxfreq,
+                           w->maxintg);
+    }
+    GC_HIP(hipGetLastError());
+    w->ran = true;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_acq_fetch(gnsscorr_ctx *ctx, gnsscorr_acqres_t *res)
+{
+    if (!ctx || !ctx->acq || !ctx->acq->ran) return gc_fail(GNSSCORR_ESTATE, "acq_fetch: no acq_run yet");
+    if (!res) return gc_fail(GNSSCORR_EINVAL, "acq_fetch: null result array");
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipMemcpyAsync(res, ctx->acq->res, sizeof(gnsscorr_acqres_t) * ctx->nch, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
+{
+    if (!ctx || !ctx->acq || !ctx->acq->ran) return gc_fail(GNSSCORR_ESTATE, "acq_power: no acq_run yet");
+    if (ch < 0 || ch >= ctx->nch || !power) return gc_fail(GNSSCORR_EINVAL, "acq_power: channel %d", ch);
+    GC_HIP(hipSetDevice(ctx->device));
+    GcAcqWork *w = ctx->acq;
+    const GcChan &c = ctx->hchan[ch];
+    const size_t elems = (size_t)c.nfreq * c.nsamp;
+    if (elems > w->P_elems) {
+        hipFree(w->P); w->P = nullptr; w->P_elems = 0;
+        GC_HIP(hipMalloc((void **)&w->P, sizeof(double) * elems));
+        w->P_elems = elems;
+    }
+    // iteration count of the last run is still in w->iters[ch]; rows of this channel are rewritten
+    // with identical values
+    hipLaunchKernelGGL(acq_corr_kernel, dim3(c.nfreq, 1), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
+                       ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, w->P, ch, w->maxfreq,
+                       w->maxintg, w->Es);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_fft16k(gnsscorr_ctx *ctx, const void *in, void *out, int sign, int batch)
+{
+    if (!ctx || !in || !out || batch <= 0) return gc_fail(GNSSCORR_EINVAL, "fft16k: bad arguments");
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = acq_tables(ctx);
+    if (rc) return rc;
+    GcAcqWork *w = ctx->acq;
+    GcTimed t(ctx, "fft16k");
+    if (sign < 0)
+        hipLaunchKernelGGL(fft16k_kernel<-1>, dim3(batch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
+                           (const float2 *)in, (float2 *)out, w->tw16k);
+    else
+        hipLaunchKernelGGL(fft16k_kernel<+1>, dim3(batch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
+                           (const float2 *)in, (float2 *)out, w->tw16k);
+    GC_HIP(hipGetLastError());
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_pspec(gnsscorr_ctx *ctx, const float *cpx, int n, int flagsum, double *pspec)
+{
+    if (!ctx || !cpx || !pspec) return gc_fail(GNSSCORR_EINVAL, "pspec: bad arguments");
+    if (n != GC_LH && n != GC_L) return gc_fail(GNSSCORR_EINVAL, "pspec: n %d (16384 or 32768 supported)", n);
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = acq_tables(ctx);
+    if (rc) return rc;
+    GcAcqWork *w = ctx->acq;
+    float2 *din = nullptr;
+    double *dps = nullptr;
+    GC_HIP(hipMalloc((void **)&din, sizeof(float2) * n));
+    if (hipMalloc((void **)&dps, sizeof(double) * n) != hipSuccess) { hipFree(din); return gc_fail(GNSSCORR_EHIP, "pspec: hipMalloc"); }
+    hipMemcpyAsync(din, cpx, sizeof(float2) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (flagsum) hipMemcpyAsync(dps, pspec, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(pspec_kernel, dim3(1), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream, din, n,
+                       w->tw16k, w->tw32k, dps, flagsum);
+    hipError_t e = hipGetLastError();
+    hipMemcpyAsync(pspec, dps, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(din); hipFree(dps);
+    if (e != hipSuccess) return gc_fail_hip(e, "pspec_kernel", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return gc_fail_hip(e2, "pspec sync", __FILE__, __LINE__);
+    return GNSSCORR_OK;
+}

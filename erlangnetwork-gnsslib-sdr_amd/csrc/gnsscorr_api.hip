@@ -1,0 +1,474 @@
+// gnsscorr_api.hip -- C-ABI layer of libgnsscorr.so: context, IF ring in HBM,
+// channel tables, batched tracking entry points, per-kernel timing.
+// (Acquisition entry points live in gnsscorr_acq.hip, the reference-named
+// per-call symbols in gnsscorr_compat.hip.)
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gnsscorr_ctx.h"
+
+static thread_local char g_err[512] = "";
+
+int gc_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int gc_fail_hip(hipError_t e, const char *what, const char *file, int line)
+{
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what,
+             file, line);
+    return GNSSCORR_EHIP;
+}
+
+extern "C" const char *gnsscorr_last_error(void) { return g_err; }
+
+extern "C" int gnsscorr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gnsscorr_create(gnsscorr_ctx **out, int device, void *stream)
+{
+    if (!out) return gc_fail(GNSSCORR_EINVAL, "gnsscorr_create: null out pointer");
+    int ndev = 0;
+    GC_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return gc_fail(GNSSCORR_EHIP, "gnsscorr_create: device %d not present (%d visible)", device, ndev);
+    GC_HIP(hipSetDevice(device));
+    gnsscorr_ctx *ctx = new gnsscorr_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return gc_fail_hip(e, "hipStreamCreate", __FILE__, __LINE__); }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return GNSSCORR_OK;
+}
+
+static void free_channels(gnsscorr_ctx *ctx)
+{
+    hipFree(ctx->dchan);  ctx->dchan = nullptr;
+    hipFree(ctx->dcodes); ctx->dcodes = nullptr;
+    hipFree(ctx->dfreqs); ctx->dfreqs = nullptr;
+    hipFree(ctx->dstate); ctx->dstate = nullptr;
+}
+
+static void free_trk_buffers(gnsscorr_ctx *ctx)
+{
+    hipFree(ctx->dplan);  ctx->dplan = nullptr;
+    hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
+    hipFree(ctx->dcorrQ); ctx->dcorrQ = nullptr;
+    hipFree(ctx->dnsamp); ctx->dnsamp = nullptr;
+    hipFree(ctx->dsumI);  ctx->dsumI = nullptr;
+    hipFree(ctx->dsumQ);  ctx->dsumQ = nullptr;
+    ctx->plan_cap = 0;
+}
+
+extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    gc_acq_free(ctx);
+    free_trk_buffers(ctx);
+    free_channels(ctx);
+    for (auto &r : ctx->ring)
+        if (r.owned && r.mem) hipFree(r.mem);
+    for (auto &kv : ctx->timers)
+        for (auto &p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void *gnsscorr_stream(gnsscorr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int gnsscorr_sync(gnsscorr_ctx *ctx)
+{
+    if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// IF ring
+// ---------------------------------------------------------------------------
+static GcRing *ring_of(gnsscorr_ctx *ctx, int ftype)
+{
+    if (!ctx || ftype < 1 || ftype > 2) return nullptr;
+    return &ctx->ring[ftype - 1];
+}
+
+static void retarget_rings(gnsscorr_ctx *ctx);
+
+extern "C" int gnsscorr_ring_create(gnsscorr_ctx *ctx, int ftype, int dtype, uint64_t ringlen,
+                                    void *devmem)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    if (!r) return gc_fail(GNSSCORR_EINVAL, "ring_create: bad context or ftype %d", ftype);
+    if (dtype != 1 && dtype != 2) return gc_fail(GNSSCORR_EINVAL, "ring_create: dtype %d not 1 or 2", dtype);
+    if (ringlen == 0 || ((uint64_t)dtype * ringlen) % 16 != 0)
+        return gc_fail(GNSSCORR_EINVAL, "ring_create: dtype*ringlen must be a positive multiple of 16");
+    if (devmem && ((uintptr_t)devmem & 15))
+        return gc_fail(GNSSCORR_EINVAL, "ring_create: device buffer must be 16-byte aligned");
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (r->owned && r->mem) hipFree(r->mem);
+    r->mem = nullptr;
+    r->owned = false;
+    if (devmem) {
+        r->mem = (int8_t *)devmem;
+    } else {
+        GC_HIP(hipMalloc((void **)&r->mem, (size_t)dtype * ringlen));
+        GC_HIP(hipMemsetAsync(r->mem, 0, (size_t)dtype * ringlen, ctx->stream));
+        r->owned = true;
+    }
+    r->dtype = dtype;
+    r->ringlen = ringlen;
+    r->wrpos = 0;
+    retarget_rings(ctx);
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_ring_push(gnsscorr_ctx *ctx, int ftype, const void *host, uint64_t nsamp)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    if (!r || !r->mem) return gc_fail(GNSSCORR_ESTATE, "ring_push: ring %d not created", ftype);
+    if (nsamp > r->ringlen) return gc_fail(GNSSCORR_EINVAL, "ring_push: chunk larger than the ring");
+    GC_HIP(hipSetDevice(ctx->device));
+    const uint64_t d = (uint64_t)r->dtype;
+    const uint64_t pos = r->wrpos % r->ringlen;
+    const uint64_t first = (pos + nsamp <= r->ringlen) ? nsamp : r->ringlen - pos;
+    const int8_t *h = (const int8_t *)host;
+    GC_HIP(hipMemcpyAsync(r->mem + d * pos, h, d * first, hipMemcpyHostToDevice, ctx->stream));
+    if (first < nsamp)
+        GC_HIP(hipMemcpyAsync(r->mem, h + d * first, d * (nsamp - first), hipMemcpyHostToDevice,
+                              ctx->stream));
+    // the host buffer may be reused by the caller as soon as we return
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    r->wrpos += nsamp;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_ring_commit(gnsscorr_ctx *ctx, int ftype, uint64_t nsamp)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    if (!r || !r->mem) return gc_fail(GNSSCORR_ESTATE, "ring_commit: ring %d not created", ftype);
+    r->wrpos += nsamp;
+    return GNSSCORR_OK;
+}
+
+extern "C" uint64_t gnsscorr_ring_wrpos(gnsscorr_ctx *ctx, int ftype)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    return r ? r->wrpos : 0;
+}
+
+extern "C" void *gnsscorr_ring_devptr(gnsscorr_ctx *ctx, int ftype)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    return r ? (void *)r->mem : nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// channels
+// ---------------------------------------------------------------------------
+static int upload_channels(gnsscorr_ctx *ctx)
+{
+    GC_HIP(hipMemcpyAsync(ctx->dchan, ctx->hchan.data(), sizeof(GcChan) * ctx->nch, hipMemcpyHostToDevice,
+                          ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+static void retarget_rings(gnsscorr_ctx *ctx)
+{
+    if (!ctx->nch || !ctx->dchan) return;
+    for (int i = 0; i < ctx->nch; i++) {
+        const GcRing &r = ctx->ring[ctx->hdesc[i].ftype - 1];
+        ctx->hchan[i].ring = r.mem;
+        ctx->hchan[i].ringlen = r.ringlen;
+    }
+    upload_channels(ctx);
+}
+
+extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_chan_t *ch)
+{
+    if (!ctx || nch <= 0 || !ch) return gc_fail(GNSSCORR_EINVAL, "set_channels: bad arguments");
+    GC_HIP(hipSetDevice(ctx->device));
+    // validate first: nothing is touched on failure
+    for (int i = 0; i < nch; i++) {
+        const gnsscorr_chan_t &c = ch[i];
+        if (c.dtype != 1 && c.dtype != 2) return gc_fail(GNSSCORR_EINVAL, "channel %d: dtype %d", i, c.dtype);
+        if (c.ftype != 1 && c.ftype != 2) return gc_fail(GNSSCORR_EINVAL, "channel %d: ftype %d", i, c.ftype);
+        if (c.clen <= 0 || c.clen > 1023 || !c.code)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: code length %d (1..1023 supported)", i, c.clen);
+        if (c.corrn < 1 || 1 + 2 * c.corrn > GNSSCORR_MAXTAPS || !c.corrp)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: corrn %d (1..16 supported)", i, c.corrn);
+        if (c.corrn != ch[0].corrn)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: corrn differs (one [TRACK] CORRN per receiver)", i);
+        if (c.nfreq < 1 || c.nfreq > GNSSCORR_MAXFREQ || !c.freq)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: nfreq %d", i, c.nfreq);
+        if (c.nsamp <= 0 || c.nsamp > 16384)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: nsamp %d (acquisition FFT supports <= 16384)", i, c.nsamp);
+        for (int k = 0; k < c.corrn; k++)
+            if (c.corrp[k] <= 0 || (k && c.corrp[k] <= c.corrp[k - 1]))
+                return gc_fail(GNSSCORR_EINVAL, "channel %d: corrp must be positive and increasing", i);
+        const GcRing &r = ctx->ring[c.ftype - 1];
+        if (!r.mem) return gc_fail(GNSSCORR_ESTATE, "channel %d: ring %d not created", i, c.ftype);
+        if (r.dtype != c.dtype)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: dtype %d but ring %d holds dtype %d", i, c.dtype, c.ftype, r.dtype);
+    }
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    gc_acq_free(ctx);
+    free_trk_buffers(ctx);
+    free_channels(ctx);
+
+    ctx->nch = nch;
+    ctx->hdesc.assign(ch, ch + nch);
+    ctx->hcode.resize(nch);
+    ctx->hfreq.resize(nch);
+    ctx->hcorrp.resize(nch);
+    ctx->hchan.assign(nch, GcChan());
+    std::vector<int8_t> codes((size_t)nch * 1024, 0);
+    std::vector<double> freqs;
+    ctx->ntap = 1 + 2 * ch[0].corrn;
+    ctx->smax_max = 0;
+    ctx->max_n = 0;
+    int ngrid = 0;
+    for (int i = 0; i < nch; i++) {
+        gnsscorr_chan_t &d = ctx->hdesc[i];
+        ctx->hcode[i].assign(d.code, d.code + d.clen);
+        ctx->hfreq[i].assign(d.freq, d.freq + d.nfreq);
+        ctx->hcorrp[i].assign(d.corrp, d.corrp + d.corrn);
+        d.code = ctx->hcode[i].data();
+        d.freq = ctx->hfreq[i].data();
+        d.corrp = ctx->hcorrp[i].data();
+        for (int k = 0; k < d.clen; k++) codes[(size_t)i * 1024 + k] = (int8_t)d.code[k];
+        GcChan &g = ctx->hchan[i];
+        g.dtype = d.dtype; g.clen = d.clen; g.nsamp = d.nsamp; g.nsampchip = d.nsampchip;
+        g.ntap = 1 + 2 * d.corrn;
+        g.smax = d.corrp[d.corrn - 1];
+        g.tapoff[0] = 0;
+        for (int k = 0; k < d.corrn; k++) { g.tapoff[1 + 2 * k] = -d.corrp[k]; g.tapoff[2 + 2 * k] = d.corrp[k]; }
+        g.ti = d.ti; g.f_sf = d.f_sf; g.crate = d.crate; g.ctime = d.ctime;
+        g.nfreq = d.nfreq; g.intg = d.intg; g.nfft = d.nfft;
+        g.freq_off = (int)freqs.size();
+        freqs.insert(freqs.end(), d.freq, d.freq + d.nfreq);
+        // acquisition grid = channels that share ring, sample grid and Doppler bins
+        g.grid = -1;
+        for (int j = 0; j < i && g.grid < 0; j++) {
+            const gnsscorr_chan_t &o = ctx->hdesc[j];
+            if (o.ftype == d.ftype && o.dtype == d.dtype && o.nsamp == d.nsamp && o.nfreq == d.nfreq &&
+                o.intg == d.intg && o.ti == d.ti && o.nfft == d.nfft &&
+                !memcmp(o.freq, d.freq, sizeof(double) * d.nfreq))
+                g.grid = ctx->hchan[j].grid;
+        }
+        if (g.grid < 0) g.grid = ngrid++;
+        if (g.smax > ctx->smax_max) ctx->smax_max = g.smax;
+        if (d.nsamp + 100 > ctx->max_n) ctx->max_n = d.nsamp + 100;   // ref src/sdrtrk.c:23
+    }
+    GC_HIP(hipMalloc((void **)&ctx->dchan, sizeof(GcChan) * nch));
+    GC_HIP(hipMalloc((void **)&ctx->dcodes, codes.size()));
+    GC_HIP(hipMalloc((void **)&ctx->dfreqs, sizeof(double) * freqs.size()));
+    GC_HIP(hipMalloc((void **)&ctx->dstate, sizeof(GcTrkState) * nch));
+    GC_HIP(hipMemsetAsync(ctx->dstate, 0, sizeof(GcTrkState) * nch, ctx->stream));
+    GC_HIP(hipMemcpyAsync(ctx->dcodes, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipMemcpyAsync(ctx->dfreqs, freqs.data(), sizeof(double) * freqs.size(), hipMemcpyHostToDevice,
+                          ctx->stream));
+    for (int i = 0; i < nch; i++) {
+        const GcRing &r = ctx->ring[ctx->hdesc[i].ftype - 1];
+        ctx->hchan[i].ring = r.mem;
+        ctx->hchan[i].ringlen = r.ringlen;
+        ctx->hchan[i].code = ctx->dcodes + (size_t)i * 1024;
+    }
+    return upload_channels(ctx);
+}
+
+extern "C" int gnsscorr_num_channels(gnsscorr_ctx *ctx) { return ctx ? ctx->nch : 0; }
+
+// ---------------------------------------------------------------------------
+// tracking
+// ---------------------------------------------------------------------------
+extern "C" int gnsscorr_trk_set_state(gnsscorr_ctx *ctx, int ch0, int nch, const gnsscorr_trkstate_t *st)
+{
+    if (!ctx || !st || ch0 < 0 || nch <= 0 || ch0 + nch > ctx->nch)
+        return gc_fail(GNSSCORR_EINVAL, "trk_set_state: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
+    static_assert(sizeof(gnsscorr_trkstate_t) == sizeof(GcTrkState), "state layout");
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipMemcpyAsync(ctx->dstate + ch0, st, sizeof(GcTrkState) * nch, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch, gnsscorr_trkstate_t *st)
+{
+    if (!ctx || !st || ch0 < 0 || nch <= 0 || ch0 + nch > ctx->nch)
+        return gc_fail(GNSSCORR_EINVAL, "trk_get_state: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipMemcpyAsync(st, ctx->dstate + ch0, sizeof(GcTrkState) * nch, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
+{
+    const size_t units = (size_t)ctx->nch * nepoch;
+    if (units <= ctx->plan_cap) return GNSSCORR_OK;
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    free_trk_buffers(ctx);
+    GC_HIP(hipMalloc((void **)&ctx->dplan, sizeof(GcTrkPlan) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
+    GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
+    GC_HIP(hipMalloc((void **)&ctx->dnsamp, sizeof(int) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));
+    GC_HIP(hipMalloc((void **)&ctx->dsumQ, sizeof(double) * ctx->nch * ctx->ntap));
+    ctx->plan_cap = units;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
+{
+    if (!ctx || nepoch <= 0) return gc_fail(GNSSCORR_EINVAL, "trk_run: nepoch %d", nepoch);
+    if (!ctx->nch) return gc_fail(GNSSCORR_ESTATE, "trk_run: no channels set");
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_trk_buffers(ctx, nepoch);
+    if (rc) return rc;
+    {
+        GcTimed t(ctx, "trk_plan");
+        rc = gc_launch_trk_plan(ctx->stream, ctx->dchan, ctx->dstate, ctx->dplan, ctx->nch, nepoch);
+        if (rc) return rc;
+    }
+    bool have[3] = {false, false, false};
+    for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
+    for (int dtype = 1; dtype <= 2; dtype++) {
+        if (!have[dtype]) continue;
+        GcTimed t(ctx, "trk_corr");
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dplan, ctx->dcorrI, ctx->dcorrQ, ctx->dnsamp,
+                                ctx->nch, nepoch, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+        if (rc) return rc;
+    }
+    {
+        GcTimed t(ctx, "trk_sums");
+        rc = gc_launch_trk_sums(ctx->stream, ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ, ctx->nch,
+                                nepoch, ctx->ntap);
+        if (rc) return rc;
+    }
+    ctx->last_nepoch = nepoch;
+    return GNSSCORR_OK;
+}
+
+// trk.II <- correlator's QQ (sum dataQ*code), trk.QQ <- its II: ref src/sdrtrk.c:42
+extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQQ, int *nsamp_out)
+{
+    if (!ctx || !ctx->last_nepoch) return gc_fail(GNSSCORR_ESTATE, "trk_fetch: no completed trk_run");
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t units = (size_t)ctx->nch * ctx->last_nepoch;
+    if (trkII)
+        GC_HIP(hipMemcpyAsync(trkII, ctx->dcorrQ, sizeof(double) * units * ctx->ntap, hipMemcpyDeviceToHost, ctx->stream));
+    if (trkQQ)
+        GC_HIP(hipMemcpyAsync(trkQQ, ctx->dcorrI, sizeof(double) * units * ctx->ntap, hipMemcpyDeviceToHost, ctx->stream));
+    if (nsamp_out)
+        GC_HIP(hipMemcpyAsync(nsamp_out, ctx->dnsamp, sizeof(int) * units, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ)
+{
+    if (!ctx || !ctx->last_nepoch) return gc_fail(GNSSCORR_ESTATE, "trk_fetch_sums: no completed trk_run");
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->nch * ctx->ntap;
+    if (sumI) GC_HIP(hipMemcpyAsync(sumI, ctx->dsumQ, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (sumQ) GC_HIP(hipMemcpyAsync(sumQ, ctx->dsumI, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ)
+{
+    if (!ctx || !ctx->dcorrI) return gc_fail(GNSSCORR_ESTATE, "trk_devptrs: no trk_run yet");
+    if (trkII) *trkII = ctx->dcorrQ;
+    if (trkQQ) *trkQQ = ctx->dcorrI;
+    return GNSSCORR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------
+static void drain_timers(gnsscorr_ctx *ctx)
+{
+    for (auto &kv : ctx->timers) {
+        for (auto &p : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.launches++;
+            }
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+extern "C" int gnsscorr_timing_enable(gnsscorr_ctx *ctx, int on)
+{
+    if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
+    ctx->timing = on != 0;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_timing_reset(gnsscorr_ctx *ctx)
+{
+    if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    ctx->timers.clear();
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_timing_read(gnsscorr_ctx *ctx, const char *kernel, double *total_ms, int *launches)
+{
+    if (!ctx || !kernel) return gc_fail(GNSSCORR_EINVAL, "timing_read: bad arguments");
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    auto it = ctx->timers.find(kernel);
+    if (total_ms) *total_ms = it == ctx->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;
+    return GNSSCORR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// process-wide context for the reference-named per-call symbols
+// ---------------------------------------------------------------------------
+extern "C" gnsscorr_ctx *gnsscorr_default_ctx(void)
+{
+    static std::mutex m;
+    static gnsscorr_ctx *g = nullptr;
+    std::lock_guard<std::mutex> lk(m);
+    if (!g) {
+        const char *e = getenv("GNSSCORR_DEVICE");
+        int dev = e ? atoi(e) : 0;
+        if (gnsscorr_create(&g, dev, nullptr) != GNSSCORR_OK) {
+            fprintf(stderr, "error: gnsscorr: %s\n", gnsscorr_last_error());
+            g = nullptr;
+        }
+    }
+    return g;
+}

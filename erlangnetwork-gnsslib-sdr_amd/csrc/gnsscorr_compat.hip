@@ -1,0 +1,186 @@
+// gnsscorr_compat.hip -- the reference's own per-call symbols (one channel,
+// one code period / one acquisition attempt per call), implemented on the HIP
+// kernels through the process-wide default context.  Signatures and side
+// effects follow the reference (cited per function); see INTEGRATION.md for
+// how they replace src/sdracq.c, src/sdrtrk.c and the helpers in
+// src/sdrcmn.c when linking the reference's channel thread.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+
+#include "../../include/sdr_compat.h"
+#include "gnsscorr_ctx.h"
+
+#define SDRPRINTF printf
+
+// per-call scratch on the default context (guarded by ctx->mtx)
+struct GcOnce {
+    int8_t *data = nullptr;  size_t data_cap = 0;    // scratch "ring" for host-supplied samples
+    int8_t *code = nullptr;                          // 1024 chips
+    GcChan *chan = nullptr;
+    GcTrkPlan *plan = nullptr;
+    double *out = nullptr;                           // 2*GNSSCORR_MAXTAPS
+};
+static GcOnce g_once;
+
+static int once_init(gnsscorr_ctx *ctx)
+{
+    if (g_once.chan) return 0;
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipMalloc((void **)&g_once.code, 1024));
+    GC_HIP(hipMalloc((void **)&g_once.chan, sizeof(GcChan)));
+    GC_HIP(hipMalloc((void **)&g_once.plan, sizeof(GcTrkPlan)));
+    GC_HIP(hipMalloc((void **)&g_once.out, sizeof(double) * 2 * GNSSCORR_MAXTAPS));
+    return 0;
+}
+
+// closed-form NCO remainders on the host; same operations as the device
+// planner (gnsscorr_trk.hip) -- contraction off so that mul/add stay separate
+#pragma clang fp contract(off)
+static void host_rems(double phi0, double freq, double ti, int n, double coff, int smax, double ci,
+                      int len, double *remc, double *remp)
+{
+    const double phis = phi0 * GC_CDIV / GC_DPI;
+    const double ps = freq * GC_CDIV * ti;
+    double prem = std::fma((double)n, ps, phis) * GC_DPI / GC_CDIV;
+    if (prem > GC_DPI) prem = std::fma(-std::floor(prem / GC_DPI), GC_DPI, prem);
+    *remp = prem;
+
+    double cs = coff - smax * ci;
+    cs -= std::floor(cs / len) * len;
+    const int nt = n + 2 * smax;
+    double wraps = 0.0;
+    if (nt > 0) wraps = (double)((long long)std::fma((double)(nt - 1), ci, cs) / len);
+    const double cend = std::fma((double)nt, ci, cs) - wraps * len;
+    *remc = cend - smax * ci;
+}
+
+// One (channel, period) unit on samples that already sit in a device ring.
+static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, int dtype, double ti,
+                     int n, double freq, double phi0, double crate, double coff, const int *s, int ns,
+                     const short *codein, int coden, uint64_t buffloc, double *cI, double *cQ)
+{
+    if (ns < 1 || 1 + 2 * ns > GNSSCORR_MAXTAPS) return gc_fail(GNSSCORR_EINVAL, "correlator: ns %d", ns);
+    if (coden < 1 || coden > 1023) return gc_fail(GNSSCORR_EINVAL, "correlator: code length %d", coden);
+    if (n < 1) return gc_fail(GNSSCORR_EINVAL, "correlator: n %d", n);
+    int rc = once_init(ctx);
+    if (rc) return rc;
+    GcChan c;
+    memset(&c, 0, sizeof(c));
+    c.ring = ring; c.ringlen = ringlen; c.code = g_once.code;
+    c.dtype = dtype; c.clen = coden; c.nsamp = n; c.ntap = 1 + 2 * ns; c.smax = s[ns - 1];
+    c.tapoff[0] = 0;
+    for (int k = 0; k < ns; k++) { c.tapoff[1 + 2 * k] = -s[k]; c.tapoff[2 + 2 * k] = s[k]; }
+    c.ti = ti;
+    GcTrkPlan p;
+    memset(&p, 0, sizeof(p));
+    p.buffloc = buffloc; p.coff = coff; p.phi0 = phi0; p.carrfreq = freq; p.codefreq = crate; p.n = n;
+    int8_t chips[1024] = {0};
+    for (int i = 0; i < coden; i++) chips[i] = (int8_t)codein[i];
+    GC_HIP(hipMemcpyAsync(g_once.code, chips, 1024, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipMemcpyAsync(g_once.chan, &c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipMemcpyAsync(g_once.plan, &p, sizeof(p), hipMemcpyHostToDevice, ctx->stream));
+    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.plan, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
+                            nullptr, 1, 1, c.ntap, dtype, c.ntap, n, c.smax);
+    if (rc) return rc;
+    double host[2 * GNSSCORR_MAXTAPS];
+    GC_HIP(hipMemcpyAsync(host, g_once.out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(cI, host, sizeof(double) * c.ntap);
+    memcpy(cQ, host + GNSSCORR_MAXTAPS, sizeof(double) * c.ntap);
+    return 0;
+}
+
+extern "C" {
+
+// ref src/sdrcmn.c:687-722.  On failure prints an error and leaves the
+// outputs untouched, like the reference's allocation-failure path (:697-702).
+void correlator(const char *data, int dtype, double ti, int n, double freq, double phi0, double crate,
+                double coff, int *s, int ns, double *II, double *QQ, double *remc, double *remp,
+                short *codein, int coden)
+{
+    gnsscorr_ctx *ctx = gnsscorr_default_ctx();
+    if (!ctx) { SDRPRINTF("error: correlator: no GPU context (%s)\n", gnsscorr_last_error()); return; }
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (hipSetDevice(ctx->device) != hipSuccess) { SDRPRINTF("error: correlator: hipSetDevice\n"); return; }
+    const size_t bytes = (((size_t)n * dtype + 15) & ~(size_t)15) + 32;
+    if (bytes > g_once.data_cap) {
+        if (g_once.data) hipFree(g_once.data);
+        g_once.data = nullptr; g_once.data_cap = 0;
+        if (hipMalloc((void **)&g_once.data, bytes) != hipSuccess) {
+            SDRPRINTF("error: correlator memory allocation\n");
+            return;
+        }
+        g_once.data_cap = bytes;
+    }
+    if (hipMemcpyAsync(g_once.data, data, (size_t)n * dtype, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        SDRPRINTF("error: correlator: sample upload failed\n");
+        return;
+    }
+    double cI[GNSSCORR_MAXTAPS], cQ[GNSSCORR_MAXTAPS];
+    const uint64_t ringlen = g_once.data_cap / dtype;      // multiple of 16 bytes by construction
+    if (corr_unit(ctx, g_once.data, ringlen, dtype, ti, n, freq, phi0, crate, coff, s, ns, codein, coden, 0,
+                  cI, cQ)) {
+        SDRPRINTF("error: correlator: %s\n", gnsscorr_last_error());
+        return;
+    }
+    memcpy(II, cI, sizeof(double) * (1 + 2 * ns));
+    memcpy(QQ, cQ, sizeof(double) * (1 + 2 * ns));
+    host_rems(phi0, freq, ti, n, coff, s[ns - 1], ti * crate, coden, remc, remp);
+}
+
+// ref src/sdrtrk.c:15-54.  Samples come from the HBM mirror of the ring
+// (front end sdr->ftype) instead of rcvgetbuff().
+uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt)
+{
+    uint64_t bufflocnow;
+    sdr->flagtrk = OFF;
+
+    mlock(hreadmtx);
+    bufflocnow = sdrstat.fendbuffsize * sdrstat.buffcnt - sdr->nsamp;
+    unmlock(hreadmtx);
+
+    if (bufflocnow > buffloc) {
+        gnsscorr_ctx *ctx = gnsscorr_default_ctx();
+        if (!ctx) { SDRPRINTF("error: sdrtracking: no GPU context (%s)\n", gnsscorr_last_error()); return bufflocnow; }
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        const GcRing &r = ctx->ring[sdr->ftype == FTYPE2 ? 1 : 0];
+        if (!r.mem || r.dtype != sdr->dtype) {
+            SDRPRINTF("error: sdrtracking: IF ring %d is not mirrored on the GPU\n", sdr->ftype);
+            return bufflocnow;
+        }
+        sdr->currnsamp = (int)((sdr->clen - sdr->trk.remcode) / (sdr->trk.codefreq / sdr->f_sf));
+
+        // the reference copies 1+2*corrn*sizeof(double) bytes here (:35-36)
+        memcpy(sdr->trk.oldI, sdr->trk.II, 1 + 2 * sdr->trk.corrn * sizeof(double));
+        memcpy(sdr->trk.oldQ, sdr->trk.QQ, 1 + 2 * sdr->trk.corrn * sizeof(double));
+        sdr->trk.oldremcode = sdr->trk.remcode;
+        sdr->trk.oldremcarr = sdr->trk.remcarr;
+
+        double cI[GNSSCORR_MAXTAPS], cQ[GNSSCORR_MAXTAPS];
+        if (hipSetDevice(ctx->device) != hipSuccess ||
+            corr_unit(ctx, r.mem, r.ringlen, sdr->dtype, sdr->ti, sdr->currnsamp, sdr->trk.carrfreq,
+                      sdr->trk.oldremcarr, sdr->trk.codefreq, sdr->trk.oldremcode, sdr->trk.corrp,
+                      sdr->trk.corrn, sdr->code, sdr->clen, buffloc, cI, cQ)) {
+            SDRPRINTF("error: sdrtracking: %s\n", gnsscorr_last_error());
+            return bufflocnow;
+        }
+        // correlator(..., sdr->trk.QQ, sdr->trk.II, ...): the swapped hand-over of :40-43
+        const int ntap = 1 + 2 * sdr->trk.corrn;
+        memcpy(sdr->trk.QQ, cI, sizeof(double) * ntap);
+        memcpy(sdr->trk.II, cQ, sizeof(double) * ntap);
+        host_rems(sdr->trk.oldremcarr, sdr->trk.carrfreq, sdr->ti, sdr->currnsamp, sdr->trk.oldremcode,
+                  sdr->trk.corrp[sdr->trk.corrn - 1], sdr->ti * sdr->trk.codefreq, sdr->clen,
+                  &sdr->trk.remcode, &sdr->trk.remcarr);
+
+        sdrnavigation(sdr, buffloc, cnt);
+        sdr->flagtrk = ON;
+    } else {
+        usleep(1000);   // sleepms(1)
+    }
+    return bufflocnow;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// gnsscorr_internal.h -- device-side data layout shared by the tracking and
+// acquisition kernels and the C-ABI layer.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gnsscorr.h"
+
+#define GC_DPI      (2.0*3.1415926535897932)  // DPI with the reference's PI literal (ref src/sdr.h:103-104)
+#define GC_CDIV     32
+#define GC_RCPAD    16                   // guard chips either side of the resampled code in LDS
+
+// Per-channel constants (HBM, one entry per channel).
+struct GcChan {
+    const int8_t *ring;      // IF ring of the channel's front end
+    uint64_t ringlen;        // samples
+    const int8_t *code;      // clen chips (+-1) in the code pool
+    int    dtype, clen, nsamp, nsampchip;
+    int    ntap, smax;
+    int    tapoff[GNSSCORR_MAXTAPS];   // tap offsets in samples: 0,-s0,+s0,-s1,+s1,...
+    double ti, f_sf, crate, ctime;
+    // acquisition
+    int    nfreq, intg, nfft, grid;    // grid = index of the (ring, freq grid) group
+    int    freq_off;                   // offset into the frequency pool
+    int    pad0;
+};
+
+// Tracking state carried from epoch to epoch (ref sdrtrk_t, src/sdr.h:371-381).
+struct GcTrkState {
+    double   carrfreq, codefreq, remcode, remcarr;
+    uint64_t buffloc;
+};
+
+// One (channel, epoch) work unit produced by the planner.
+struct GcTrkPlan {
+    uint64_t buffloc;   // first sample of the period
+    double   coff;      // code phase at buffloc (chips)   = oldremcode
+    double   phi0;      // carrier phase at buffloc (rad)  = oldremcarr
+    double   carrfreq;  // Hz, held over the batch
+    double   codefreq;  // chip/s, held over the batch
+    int      n;         // currnsamp
+    int      pad;
+};
+
+// Row statistics of the accumulated power after one acquisition iteration.
+struct GcAcqRow {
+    double rowmax;      // max over lags (first index on ties)
+    double sum_out;     // sum outside the +-2 chip window around argmax
+    double max_out;     // maxvd() outside the window (element 0 always a candidate)
+    int    argmax;
+    int    pad;
+};
+
+#define GC_HIP(call)                                                           \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return gc_fail_hip(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+int gc_fail_hip(hipError_t e, const char *what, const char *file, int line);
+int gc_fail(int code, const char *fmt, ...);
+
+// kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
+int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state,
+                       GcTrkPlan *plan, int nch, int nepoch);
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, double *corrI,
+                       double *corrQ, int *nsamp_out, int nch, int nepoch, int ntap_stride,
+                       int dtype, int ntap, int max_n, int smax_max);
+int gc_launch_trk_sums(hipStream_t st, const double *corrI, const double *corrQ,
+                       double *sumI, double *sumQ, int nch, int nepoch, int ntap);

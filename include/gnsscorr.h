@@ -1,0 +1,175 @@
+/*
+ * gnsscorr.h -- C ABI of libgnsscorr.so, the MI355X (gfx950) correlation
+ * engine behind GNSS-SDRLIB's acquisition / tracking entry points.
+ *
+ * Two layers are exported:
+ *
+ *  1. The reference's own symbols (sdracquisition, sdrtracking, correlator,
+ *     pcorrelator, checkacquisition, ... : see sdr_compat.h).  They keep the
+ *     reference signatures and operate on the reference's sdrch_t, one channel
+ *     and one code period per call, exactly like src/sdracq.c / src/sdrtrk.c.
+ *
+ *  2. The batched, device-resident interface below.  It is what the per-call
+ *     symbols are built on and what a scheduler that wants throughput calls:
+ *     the IF sample ring lives in HBM, every channel of an epoch batch runs in
+ *     one launch, and results stay on the device until fetched.
+ *
+ * Plain C types only: no HIP or torch types appear in any signature; device
+ * pointers and streams cross as void*.
+ *
+ * Each entry point cites the reference interface it replaces as
+ * "ref <file>:<line>" (paths relative to the reference root).
+ *
+ * All functions return 0 on success and a negative GNSSCORR_E* code on
+ * failure; gnsscorr_last_error() gives the message.  Like the reference
+ * (src/sdrcmn.c:697-702) a failing call leaves its outputs untouched.
+ */
+#ifndef GNSSCORR_H
+#define GNSSCORR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNSSCORR_OK         0
+#define GNSSCORR_EINVAL    -1   /* bad argument / unsupported shape          */
+#define GNSSCORR_EHIP      -2   /* HIP runtime error (no device, OOM, ...)   */
+#define GNSSCORR_ESTATE    -3   /* call order (no ring, no channels, ...)    */
+
+#define GNSSCORR_MAXTAPS   33   /* 1 + 2*corrn, corrn <= 16                  */
+#define GNSSCORR_MAXFREQ   256  /* Doppler bins per channel                  */
+
+typedef struct gnsscorr_ctx gnsscorr_ctx;
+
+const char *gnsscorr_last_error(void);
+int  gnsscorr_device_count(void);
+
+/* One context = one GPU + one HIP stream.  stream == NULL creates a private
+ * stream; otherwise `stream` is a hipStream_t owned by the caller. */
+int  gnsscorr_create(gnsscorr_ctx **ctx, int device, void *stream);
+void gnsscorr_destroy(gnsscorr_ctx *ctx);
+void *gnsscorr_stream(gnsscorr_ctx *ctx);
+int  gnsscorr_sync(gnsscorr_ctx *ctx);
+
+/* ---- IF sample ring in HBM -------------------------------------------------
+ * Replaces sdrstat.buff / buff2 and file_getbuff() (ref src/sdrrcv.c:505-532,
+ * ring size ref src/sdr.h:134,137).  Sample index s of front end `ftype`
+ * lives at byte dtype*(s % ringlen); the write position is the reference's
+ * sdrstat.fendbuffsize*sdrstat.buffcnt.
+ * devmem == NULL allocates dtype*ringlen bytes with hipMalloc; otherwise the
+ * caller's device buffer is used (e.g. the tensor an RCCL broadcast lands
+ * in).  dtype*ringlen must be a multiple of 16. */
+int  gnsscorr_ring_create(gnsscorr_ctx *ctx, int ftype, int dtype,
+                          uint64_t ringlen, void *devmem);
+/* append nsamp samples from host memory (what file_pushtomembuf's fread
+ * delivers, ref src/sdrrcv.c:469-495) and advance the write position */
+int  gnsscorr_ring_push(gnsscorr_ctx *ctx, int ftype, const void *host,
+                        uint64_t nsamp);
+/* the ring memory was filled by someone else (RCCL, a kernel): advance only */
+int  gnsscorr_ring_commit(gnsscorr_ctx *ctx, int ftype, uint64_t nsamp);
+uint64_t gnsscorr_ring_wrpos(gnsscorr_ctx *ctx, int ftype);
+void *gnsscorr_ring_devptr(gnsscorr_ctx *ctx, int ftype);
+
+/* ---- channels ---------------------------------------------------------------
+ * The constants initsdrch() derives (ref src/sdrinit.c:583-657). */
+typedef struct {
+    int    prn, ctype;
+    int    dtype, ftype;        /* ref sdrch_t.dtype / .ftype                */
+    int    clen, nsamp, nsampchip;
+    double f_sf, f_if, foffset; /* Hz                                        */
+    double crate, ctime, ti;
+    const short *code;          /* clen chips, +-1 (ref sdrch_t.code)        */
+    int    intg;                /* ref sdracq_t.intg                         */
+    int    nfreq;               /* ref sdracq_t.nfreq (<= GNSSCORR_MAXFREQ)  */
+    const double *freq;         /* ref sdracq_t.freq                         */
+    int    nfft;                /* ref sdracq_t.nfft (= 2*nsamp)             */
+    int    corrn;               /* ref sdrtrk_t.corrn                        */
+    const int *corrp;           /* ref sdrtrk_t.corrp                        */
+} gnsscorr_chan_t;
+
+int  gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch,
+                           const gnsscorr_chan_t *ch);
+int  gnsscorr_num_channels(gnsscorr_ctx *ctx);
+
+/* ---- tracking: E/P/L correlators + carrier wipe-off ------------------------
+ * One (channel, epoch) unit is one call of the reference's correlator()
+ * (ref src/sdrcmn.c:687-722) as driven by sdrtracking() (ref
+ * src/sdrtrk.c:31-43): currnsamp from remcode/codefreq, carrier phase and
+ * code phase continued from the previous epoch. */
+typedef struct {
+    double   carrfreq, codefreq;    /* ref sdrtrk_t.carrfreq / .codefreq     */
+    double   remcode, remcarr;      /* ref sdrtrk_t.remcode / .remcarr       */
+    uint64_t buffloc;               /* sample index of the next code period  */
+} gnsscorr_trkstate_t;
+
+int  gnsscorr_trk_set_state(gnsscorr_ctx *ctx, int ch0, int nch,
+                            const gnsscorr_trkstate_t *st);
+int  gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch,
+                            gnsscorr_trkstate_t *st);
+/* Correlate `nepoch` consecutive code periods of every channel with the
+ * frequencies held (as between two loop-filter updates, ref
+ * src/sdrmain.c:272-302).  Asynchronous on the context's stream; advances the
+ * device-resident state. */
+int  gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch);
+/* Results of the last gnsscorr_trk_run, [nch][nepoch][1+2*corrn] each, in the
+ * reference's tap order {P,E1,L1,E2,L2,...}.  trkII / trkQQ are what
+ * sdrtracking() leaves in sdr->trk.II / sdr->trk.QQ (II = sum dataQ*code/32,
+ * QQ = sum dataI*code/32: the reference's swapped hand-over, ref
+ * src/sdrtrk.c:42).  nsamp_out[nch][nepoch] = currnsamp of each period.
+ * Any pointer may be NULL.  Synchronises the stream. */
+int  gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQQ,
+                        int *nsamp_out);
+/* cumsumcorr() over the epochs of the last run (ref src/sdrtrk.c:64-76):
+ * sumI/sumQ [nch][1+2*corrn] */
+int  gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ);
+/* device pointers to the result arrays of the last run (layout as fetch) */
+int  gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ);
+
+/* ---- acquisition: parallel code phase search --------------------------------
+ * For every channel: up to `intg` iterations of pcorrelator() (ref
+ * src/sdrcmn.c:738-773) over the channel's Doppler grid, accumulated
+ * non-coherently, with checkacquisition() (ref src/sdracq.c:71-95) evaluated
+ * after each iteration, as sdracquisition() does (ref src/sdracq.c:24-43). */
+typedef struct {
+    int      acqcodei, freqi;       /* ref sdracq_t                           */
+    double   acqfreq, cn0, peakr;
+    int      flagacq;               /* ref sdrch_t.flagacq                    */
+    int      iters;                 /* iterations the reference would run     */
+    uint64_t buffloc;               /* return value of sdracquisition()       */
+} gnsscorr_acqres_t;
+
+/* wrpos == 0: use each ring's current write position.  Asynchronous. */
+int  gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos);
+int  gnsscorr_acq_fetch(gnsscorr_ctx *ctx, gnsscorr_acqres_t *res);
+/* The reference's `power` array for one channel: nfreq*nsamp doubles,
+ * accumulated over res.iters iterations (re-runs the search for that channel
+ * with the iteration count of the last gnsscorr_acq_run). */
+int  gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power);
+
+/* ---- op-level device entry points (used by the per-call symbols and tests) --
+ * 16384-point complex FFT batches on device memory, unnormalised, sign -1
+ * forward / +1 backward; in/out are device pointers to float2[batch][16384] */
+int  gnsscorr_fft16k(gnsscorr_ctx *ctx, const void *in, void *out, int sign,
+                     int batch);
+/* cpxpspec (ref src/sdrcmn.c:261-276) for n = 16384 or 32768 on host data */
+int  gnsscorr_pspec(gnsscorr_ctx *ctx, const float *cpx, int n, int flagsum,
+                    double *pspec);
+
+/* per-kernel launch timing: enable, run, then read the accumulated HIP-event
+ * time of the named kernel ("trk_corr", "trk_plan", "acq_fwd", "acq_corr",
+ * "acq_code", "acq_final") */
+int  gnsscorr_timing_enable(gnsscorr_ctx *ctx, int on);
+int  gnsscorr_timing_read(gnsscorr_ctx *ctx, const char *kernel,
+                          double *total_ms, int *launches);
+int  gnsscorr_timing_reset(gnsscorr_ctx *ctx);
+
+/* the process-wide context the per-call reference symbols use (device 0 or
+ * $GNSSCORR_DEVICE); created on first use */
+gnsscorr_ctx *gnsscorr_default_ctx(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

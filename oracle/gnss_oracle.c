@@ -1,0 +1,693 @@
+/*
+ * gnss_oracle.c -- CPU restatement of GNSS-SDRLIB's acquisition + tracking
+ * correlation path (see gnss_oracle.h: TEST INFRASTRUCTURE ONLY, parity
+ * unpinned).  Every function cites the reference file:line it follows
+ * (paths relative to the reference root).
+ */
+#include "gnss_oracle.h"
+
+#include <complex.h>
+#undef I            /* parameter names below use I/Q for the two rails */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* PRN code generators                                                       */
+/* ------------------------------------------------------------------------- */
+
+/* G2 tap delays for PRN 1..210, ref src/sdrcode.c:103-125 (IS-GPS-200 /
+ * SBAS / QZSS assignment table). */
+static const short ca_delay[210] = {
+      5,   6,   7,   8,  17,  18, 139, 140, 141, 251,
+    252, 254, 255, 256, 257, 258, 469, 470, 471, 472,
+    473, 474, 509, 512, 513, 514, 515, 516, 859, 860,
+    861, 862, 863, 950, 947, 948, 950,  67, 103,  91,
+     19, 679, 225, 625, 946, 638, 161,1001, 554, 280,
+    710, 709, 775, 864, 558, 220, 397,  55, 898, 759,
+    367, 299,1018, 729, 695, 780, 801, 788, 732,  34,
+    320, 327, 389, 407, 525, 405, 221, 761, 260, 326,
+    955, 653, 699, 422, 188, 438, 959, 539, 879, 677,
+    586, 153, 792, 814, 446, 264,1015, 278, 536, 819,
+    156, 957, 159, 712, 885, 461, 248, 713, 126, 807,
+    279, 122, 197, 693, 632, 771, 467, 647, 203, 145,
+    175,  52,  21, 237, 235, 886, 657, 634, 762, 355,
+   1012, 176, 603, 130, 359, 595,  68, 386, 797, 456,
+    499, 883, 307, 127, 211, 121, 118, 163, 628, 853,
+    484, 289, 811, 202,1021, 463, 568, 904, 670, 230,
+    911, 684, 309, 644, 932,  12, 314, 891, 212, 185,
+    675, 503, 150, 395, 345, 846, 798, 992, 357, 995,
+    877, 112, 144, 476, 193, 109, 445, 291,  87, 399,
+    292, 901, 339, 208, 711, 189, 263, 537, 663, 942,
+    173, 900,  30, 500, 935, 556, 373,  85, 652, 310
+};
+
+/* ref src/sdrcode.c:101-154.  The reference keeps the two 10-stage registers
+ * in +-1 form initialised to -1 and multiplies taps; here the same registers
+ * are kept as bits (1 <-> -1) and taps are XORed.  code = -G1*G2(delayed),
+ * i.e. chip +1 where the XOR of the two output bits is 1. */
+static int gen_l1ca(int prn, short *code, int *len, double *crate)
+{
+    unsigned char g1[1023], g2[1023];
+    unsigned r1 = 0x3FF, r2 = 0x3FF;  /* bit s (0-based) = stage s+1 */
+    int i;
+    if (prn < 1 || prn > 210) return -1;
+    for (i = 0; i < 1023; i++) {
+        unsigned f1, f2;
+        g1[i] = (r1 >> 9) & 1;
+        g2[i] = (r2 >> 9) & 1;
+        f1 = ((r1 >> 2) ^ (r1 >> 9)) & 1;                       /* R1[2]*R1[9] */
+        f2 = ((r2 >> 1) ^ (r2 >> 2) ^ (r2 >> 5) ^ (r2 >> 7) ^
+              (r2 >> 8) ^ (r2 >> 9)) & 1;           /* R2[1,2,5,7,8,9] product */
+        r1 = ((r1 << 1) | f1) & 0x3FF;
+        r2 = ((r2 << 1) | f2) & 0x3FF;
+    }
+    for (i = 0; i < 1023; i++) {
+        int j = (i + 1023 - ca_delay[prn - 1]) % 1023;
+        code[i] = (g1[i] ^ g2[j]) ? 1 : -1;
+    }
+    *len = 1023;
+    *crate = 1.023e6;
+    return 0;
+}
+
+/* ref src/sdrcode.c:426-444: 9-stage register, all -1 (bit 1) at start,
+ * code[i] = -R[6], feedback R[4]*R[8]. */
+static int gen_g1(short *code, int *len, double *crate)
+{
+    unsigned r = 0x1FF;
+    int i;
+    for (i = 0; i < 511; i++) {
+        unsigned f = ((r >> 4) ^ (r >> 8)) & 1;
+        code[i] = ((r >> 6) & 1) ? 1 : -1;
+        r = ((r << 1) | f) & 0x1FF;
+    }
+    *len = 511;
+    *crate = 0.511e6;
+    return 0;
+}
+
+/* ref src/sdrcode.c:523-539.  The reference's switch has no CTYPE_G1 case
+ * (its G1 generator is unreachable); the oracle exposes it because the build
+ * needs GLONASS channels (SURVEY hard part 8). */
+int orc_gencode(int prn, int ctype, short *code, int *len, double *crate)
+{
+    switch (ctype) {
+    case ORC_CTYPE_L1CA:
+    case ORC_CTYPE_L1SBAS: return gen_l1ca(prn, code, len, crate);
+    case ORC_CTYPE_G1:     return gen_g1(code, len, crate);
+    default:               return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* carrier wipe-off                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* ref src/sdrcmn.c:643-648 */
+void orc_carrier_lut(short *cost, short *sint)
+{
+    int i;
+    for (i = 0; i < ORC_CDIV; i++) {
+        cost[i] = (short)floor(cos(ORC_DPI / ORC_CDIV * i) / ORC_CSCALE + 0.5);
+        sint[i] = (short)floor(sin(ORC_DPI / ORC_CDIV * i) / ORC_CSCALE + 0.5);
+    }
+}
+
+static inline void mix_one(const signed char *data, int dtype, int k, int idx,
+                           const short *cost, const short *sint, short *I,
+                           short *Q)
+{
+    if (dtype == 2) {          /* ref src/sdrcmn.c:652-657 */
+        int d0 = data[2 * k], d1 = data[2 * k + 1];
+        I[k] = (short)(cost[idx] * d0 - sint[idx] * d1);
+        Q[k] = (short)(sint[idx] * d0 + cost[idx] * d1);
+    } else {                   /* ref src/sdrcmn.c:659-664 */
+        int d0 = data[k];
+        I[k] = (short)(cost[idx] * d0);
+        Q[k] = (short)(sint[idx] * d0);
+    }
+}
+
+/* ref src/sdrcmn.c:666-668: one-sided wrap of the phase remainder */
+static double phase_remainder(double phi)
+{
+    double prem = phi * ORC_DPI / ORC_CDIV;
+    while (prem > ORC_DPI) prem -= ORC_DPI;
+    return prem;
+}
+
+/* ref src/sdrcmn.c:633-669, literal: phi += ps once per sample */
+double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
+                       double freq, double phi0, short *I, short *Q)
+{
+    short cost[ORC_CDIV], sint[ORC_CDIV];
+    double phi = phi0 * ORC_CDIV / ORC_DPI;
+    double ps = freq * ORC_CDIV * ti;
+    int k;
+    orc_carrier_lut(cost, sint);
+    for (k = 0; k < n; k++, phi += ps)
+        mix_one(data, dtype, k, ((int)phi) & (ORC_CDIV - 1), cost, sint, I, Q);
+    return phase_remainder(phi);
+}
+
+/* closed form implemented by the HIP kernels: phi_k = fma(k, ps, phi_0);
+ * the remainder is reduced with one floor instead of the subtract loop. */
+double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
+                      double freq, double phi0, short *I, short *Q)
+{
+    short cost[ORC_CDIV], sint[ORC_CDIV];
+    double phis = phi0 * ORC_CDIV / ORC_DPI;
+    double ps = freq * ORC_CDIV * ti;
+    double prem;
+    int k;
+    orc_carrier_lut(cost, sint);
+    for (k = 0; k < n; k++) {
+        double phi = fma((double)k, ps, phis);
+        mix_one(data, dtype, k, ((int)phi) & (ORC_CDIV - 1), cost, sint, I, Q);
+    }
+    prem = fma((double)n, ps, phis) * ORC_DPI / ORC_CDIV;
+    if (prem > ORC_DPI) prem = fma(-floor(prem / ORC_DPI), ORC_DPI, prem);
+    return prem;
+}
+
+/* ------------------------------------------------------------------------- */
+/* code resampling                                                           */
+/* ------------------------------------------------------------------------- */
+
+/* ref src/sdrcmn.c:608-621, literal */
+double orc_rescode_seq(const short *code, int len, double coff, int smax,
+                       double ci, int n, short *rcode)
+{
+    int j;
+    coff -= smax * ci;
+    coff -= floor(coff / len) * len;
+    for (j = 0; j < n + 2 * smax; j++, coff += ci) {
+        if (coff >= len) coff -= len;
+        rcode[j] = code[(int)coff];
+    }
+    return coff - smax * ci;
+}
+
+/* closed form implemented by the HIP kernels: c_j = fma(j, ci, c_0),
+ * chip = trunc(c_j) mod len; the returned remainder subtracts exactly the
+ * wraps the reference loop would have applied (those seen at the top of its
+ * last iteration), so it may be >= len like the reference's. */
+double orc_rescode_cf(const short *code, int len, double coff, int smax,
+                      double ci, int n, short *rcode)
+{
+    int j, nt = n + 2 * smax;
+    double cend, wraps = 0.0;
+    coff -= smax * ci;
+    coff -= floor(coff / len) * len;
+    for (j = 0; j < nt; j++) {
+        long long t = (long long)fma((double)j, ci, coff);
+        rcode[j] = code[t % len];
+    }
+    if (nt > 0) wraps = (double)((long long)fma((double)(nt - 1), ci, coff) / len);
+    cend = fma((double)nt, ci, coff) - wraps * len;
+    return cend - smax * ci;
+}
+
+/* ------------------------------------------------------------------------- */
+/* tracking correlator                                                       */
+/* ------------------------------------------------------------------------- */
+
+/* ref src/sdrcmn.c:287-354 (dot_22 / dot_23): double accumulators of
+ * short*short products; one generic routine covers both tap counts. */
+static void dot_taps(const short *a1, const short *a2, const short *const *b,
+                     int nb, int n, double *d1, double *d2)
+{
+    int i, k;
+    for (i = 0; i < nb; i++) d1[i] = d2[i] = 0.0;
+    for (k = 0; k < n; k++)
+        for (i = 0; i < nb; i++) {
+            d1[i] += a1[k] * b[i][k];
+            d2[i] += a2[k] * b[i][k];
+        }
+}
+
+/* ref src/sdrcmn.c:687-722 */
+void orc_correlator(const signed char *data, int dtype, double ti, int n,
+                    double freq, double phi0, double crate, double coff,
+                    const int *s, int ns, double *II, double *QQ,
+                    double *remc, double *remp, const short *codein, int coden,
+                    int mode)
+{
+    int smax = s[ns - 1], i;
+    short *dI = (short *)malloc(sizeof(short) * (size_t)(n + 64));
+    short *dQ = (short *)malloc(sizeof(short) * (size_t)(n + 64));
+    short *ce = (short *)malloc(sizeof(short) * (size_t)(n + 2 * smax + 1));
+    const short *code, *b[3];
+    if (!dI || !dQ || !ce) { free(dI); free(dQ); free(ce); return; }
+    code = ce + smax;
+
+    if (mode) {
+        *remp = orc_mixcarr_cf(data, dtype, ti, n, freq, phi0, dI, dQ);
+        *remc = orc_rescode_cf(codein, coden, coff, smax, ti * crate, n, ce);
+    } else {
+        *remp = orc_mixcarr_seq(data, dtype, ti, n, freq, phi0, dI, dQ);
+        *remc = orc_rescode_seq(codein, coden, coff, smax, ti * crate, n, ce);
+    }
+    /* P, E1, L1 then (Ei, Li) pairs: ref :712-715 */
+    b[0] = code; b[1] = code - s[0]; b[2] = code + s[0];
+    dot_taps(dI, dQ, b, 3, n, II, QQ);
+    for (i = 1; i < ns; i++) {
+        b[0] = code - s[i]; b[1] = code + s[i];
+        dot_taps(dI, dQ, b, 2, n, II + 1 + i * 2, QQ + 1 + i * 2);
+    }
+    for (i = 0; i < 1 + 2 * ns; i++) {
+        II[i] *= ORC_CSCALE;
+        QQ[i] *= ORC_CSCALE;
+    }
+    free(dI); free(dQ); free(ce);
+}
+
+/* ------------------------------------------------------------------------- */
+/* FFT-based parallel code phase search                                      */
+/* ------------------------------------------------------------------------- */
+
+/* ref src/sdrcmn.c:185-195 */
+void orc_cpxcpx(const short *I, const short *Q, double scale, int n, float *cpx)
+{
+    int i;
+    for (i = 0; i < n; i++) {
+        cpx[2 * i]     = I[i] * (float)scale;
+        cpx[2 * i + 1] = Q ? Q[i] * (float)scale : 0.0f;
+    }
+}
+
+/* Mixed-radix decimation-in-time DFT for any length (the reference's FFT
+ * length 2*nsamp = 32736 = 2^5*3*11*31 is not a power of two).  Arithmetic in
+ * double, result rounded to float once: this stands in for FFTW3f, whose
+ * rounding cannot be reproduced (library absent, version unpinned). */
+typedef struct { int n, sign; double complex *w; } twtab_t;
+static __thread twtab_t g_tw[4];
+
+static const double complex *roots(int n, int sign)
+{
+    int i, slot = -1;
+    for (i = 0; i < 4; i++)
+        if (g_tw[i].w && g_tw[i].n == n && g_tw[i].sign == sign) return g_tw[i].w;
+    for (i = 0; i < 4; i++) if (!g_tw[i].w) { slot = i; break; }
+    if (slot < 0) { slot = 0; free(g_tw[0].w); g_tw[0].w = NULL; }
+    g_tw[slot].w = (double complex *)malloc(sizeof(double complex) * (size_t)n);
+    g_tw[slot].n = n; g_tw[slot].sign = sign;
+    for (i = 0; i < n; i++) {
+        double a = ORC_DPI * (double)i / (double)n;
+        g_tw[slot].w[i] = cos(a) + _Complex_I * (sign * sin(a));
+    }
+    return g_tw[slot].w;
+}
+
+static int small_factor(int n)
+{
+    int p;
+    if (n % 4 == 0) return 4;
+    if (n % 2 == 0) return 2;
+    for (p = 3; p * p <= n; p += 2) if (n % p == 0) return p;
+    return n;
+}
+
+/* out[0..n) = DFT of in[0], in[stride], ...; scratch has n entries */
+static void dft_rec(const double complex *in, int stride, int n,
+                    double complex *out, double complex *scratch,
+                    const double complex *w, int wn)
+{
+    int p, m, r, k, q;
+    if (n == 1) { out[0] = in[0]; return; }
+    p = small_factor(n);
+    m = n / p;
+    for (r = 0; r < p; r++)
+        dft_rec(in + (size_t)r * stride, stride * p, m, scratch + (size_t)r * m,
+                out + (size_t)r * m, w, wn);
+    {
+        int ws = wn / n;              /* w[ws*t] = root_n^t   */
+        int wp = wn / p;              /* w[wp*t] = root_p^t   */
+        double complex t[64];
+        if (p > 64) return;           /* primes above 64 are not needed here */
+        for (k = 0; k < m; k++) {
+            for (r = 0; r < p; r++)
+                t[r] = scratch[(size_t)r * m + k] * w[(size_t)ws * ((size_t)r * k % n)];
+            if (p == 2) {
+                out[k] = t[0] + t[1];
+                out[k + m] = t[0] - t[1];
+            } else if (p == 4) {
+                double complex j1 = w[wp];         /* root_4^1 = -+i */
+                double complex a = t[0] + t[2], b = t[0] - t[2];
+                double complex c = t[1] + t[3], d = (t[1] - t[3]) * j1;
+                out[k] = a + c;
+                out[k + m] = b + d;
+                out[k + 2 * m] = a - c;
+                out[k + 3 * m] = b - d;
+            } else {
+                for (q = 0; q < p; q++) {
+                    double complex acc = t[0];
+                    for (r = 1; r < p; r++)
+                        acc += t[r] * w[(size_t)wp * ((r * q) % p)];
+                    out[k + (size_t)q * m] = acc;
+                }
+            }
+        }
+    }
+}
+
+void orc_fft(float *cpx, int n, int sign)
+{
+    double complex *in = (double complex *)malloc(sizeof(double complex) * 3 * (size_t)n);
+    double complex *out = in + n, *scr = in + 2 * (size_t)n;
+    const double complex *w = roots(n, sign < 0 ? -1 : 1);
+    int i;
+    for (i = 0; i < n; i++) in[i] = cpx[2 * i] + _Complex_I * (double)cpx[2 * i + 1];
+    dft_rec(in, 1, n, out, scr, w, n);
+    for (i = 0; i < n; i++) {
+        cpx[2 * i]     = (float)creal(out[i]);
+        cpx[2 * i + 1] = (float)cimag(out[i]);
+    }
+    free(in);
+}
+
+/* ref src/sdrcmn.c:228-251 */
+void orc_cpxconv(float *a, const float *b, int m, int n, int flagsum,
+                 double *conv)
+{
+    float m2 = (float)m * m, re;
+    int i;
+    orc_fft(a, m, -1);
+    for (i = 0; i < m; i++) {           /* -A*conj(B): ref :236-240 */
+        float *p = a + 2 * i;
+        const float *q = b + 2 * i;
+        re   = -p[0] * q[0] - p[1] * q[1];
+        p[1] =  p[0] * q[1] - p[1] * q[0];
+        p[0] = re;
+    }
+    orc_fft(a, m, +1);
+    for (i = 0; i < n; i++) {
+        const float *p = a + 2 * i;
+        double v = (p[0] * p[0] + p[1] * p[1]) / m2;
+        if (flagsum) conv[i] += v; else conv[i] = v;
+    }
+}
+
+/* ref src/sdrcmn.c:261-276 */
+void orc_cpxpspec(float *cpx, int n, int flagsum, double *pspec)
+{
+    int i;
+    orc_fft(cpx, n, -1);
+    for (i = 0; i < n; i++) {
+        const float *p = cpx + 2 * i;
+        double v = (p[0] * p[0] + p[1] * p[1]);
+        if (flagsum) pspec[i] += v; else pspec[i] = v;
+    }
+}
+
+/* ref src/sdrinit.c:645-655 */
+void orc_codespectrum(const short *code, int clen, double ci, int nsamp,
+                      int nfft, float *xcode)
+{
+    short *rc = (short *)calloc((size_t)nfft, sizeof(short));
+    orc_rescode_seq(code, clen, 0.0, 0, ci, nsamp, rc);
+    orc_cpxcpx(rc, NULL, 1.0, nfft, xcode);
+    orc_fft(xcode, nfft, -1);
+    free(rc);
+}
+
+/* ref src/sdrcmn.c:738-773.  dataR is a full copy of the 2n input samples
+ * (m = 2n: the "zero padding" memset is overwritten completely). */
+void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
+                     const double *freq, int nfreq, double crate, int m,
+                     const float *codex, double *P, int mode)
+{
+    signed char *dR = (signed char *)calloc((size_t)m * dtype, 1);
+    short *dI = (short *)malloc(sizeof(short) * (size_t)(m + 64));
+    short *dQ = (short *)malloc(sizeof(short) * (size_t)(m + 64));
+    float *dx = (float *)malloc(sizeof(float) * 2 * (size_t)m);
+    int i;
+    (void)crate;
+    memcpy(dR, data, (size_t)2 * n * dtype);
+    for (i = 0; i < nfreq; i++) {
+        if (mode) orc_mixcarr_cf(dR, dtype, ti, m, freq[i], 0.0, dI, dQ);
+        else      orc_mixcarr_seq(dR, dtype, ti, m, freq[i], 0.0, dI, dQ);
+        orc_cpxcpx(dI, dQ, ORC_CSCALE / m, m, dx);
+        orc_cpxconv(dx, codex, m, n, 1, &P[(size_t)i * n]);
+    }
+    free(dR); free(dI); free(dQ); free(dx);
+}
+
+/* Direct evaluation of what pcorrelator computes (normative closed
+ * form): no FFT involved, used to cross-check the FFT route on a few lags. */
+void orc_pcorrelator_td(const signed char *data, int dtype, double ti, int n,
+                        const double *freq, int nfreq, int m,
+                        const short *code, int clen, double ci,
+                        int k0, int k1, double *P, int mode)
+{
+    short *dI = (short *)malloc(sizeof(short) * (size_t)(m + 64));
+    short *dQ = (short *)malloc(sizeof(short) * (size_t)(m + 64));
+    short *rc = (short *)malloc(sizeof(short) * (size_t)n);
+    int b, k, j;
+    orc_rescode_seq(code, clen, 0.0, 0, ci, n, rc);
+    for (b = 0; b < nfreq; b++) {
+        if (mode) orc_mixcarr_cf(data, dtype, ti, m, freq[b], 0.0, dI, dQ);
+        else      orc_mixcarr_seq(data, dtype, ti, m, freq[b], 0.0, dI, dQ);
+        for (k = k0; k < k1; k++) {
+            double sr = 0.0, si = 0.0, sc = 32.0 * (double)m;
+            for (j = 0; j < n; j++) {
+                sr += dI[k + j] * rc[j];
+                si += dQ[k + j] * rc[j];
+            }
+            P[(size_t)b * n + k] += (sr * sr + si * si) / (sc * sc);
+        }
+    }
+    free(dI); free(dQ); free(rc);
+}
+
+/* ------------------------------------------------------------------------- */
+/* acquisition decision                                                      */
+/* ------------------------------------------------------------------------- */
+
+static int outside(int i, int exinds, int exinde)
+{
+    return (exinds <= exinde && (i < exinds || i > exinde)) ||
+           (exinds >  exinde && (i < exinds && i > exinde));
+}
+
+/* ref src/sdrcmn.c:461-476: element 0 seeds the maximum even when it lies in
+ * the excluded window; strict '<' keeps the first maximum. */
+double orc_maxvd(const double *d, int n, int exinds, int exinde, int *ind)
+{
+    double mx = d[0];
+    int i;
+    *ind = 0;
+    for (i = 1; i < n; i++)
+        if (outside(i, exinds, exinde) && mx < d[i]) { mx = d[i]; *ind = i; }
+    return mx;
+}
+
+/* ref src/sdrcmn.c:487-497 */
+double orc_meanvd(const double *d, int n, int exinds, int exinde)
+{
+    double mean = 0.0;
+    int i, ne = 0;
+    for (i = 0; i < n; i++) {
+        if (outside(i, exinds, exinde)) mean += d[i]; else ne++;
+    }
+    return mean / (n - ne);
+}
+
+/* ref src/sdracq.c:71-95 (+ ind2sub src/sdrcmn.c:574-578) */
+int orc_checkacquisition(const double *P, int nsamp, int nfreq, int nsampchip,
+                         double ctime, const double *freq, orc_acqres_t *res)
+{
+    int maxi, codei, freqi, exinds, exinde, dummy;
+    double maxP, maxP2, meanP;
+    maxP = orc_maxvd(P, nsamp * nfreq, -1, -1, &maxi);
+    codei = maxi % nsamp;
+    freqi = nfreq * maxi / (nsamp * nfreq);
+    exinds = codei - 2 * nsampchip; if (exinds < 0) exinds += nsamp;
+    exinde = codei + 2 * nsampchip; if (exinde >= nsamp) exinde -= nsamp;
+    meanP = orc_meanvd(&P[(size_t)freqi * nsamp], nsamp, exinds, exinde);
+    res->cn0 = 10 * log10(maxP / meanP / ctime);
+    maxP2 = orc_maxvd(&P[(size_t)freqi * nsamp], nsamp, exinds, exinde, &dummy);
+    res->peakr = maxP / maxP2;
+    res->acqcodei = codei;
+    res->freqi = freqi;
+    res->acqfreq = freq[freqi];
+    res->acquired = res->peakr > 3.0;   /* ACQTH, ref src/sdr.h:148 */
+    return res->acquired;
+}
+
+/* ------------------------------------------------------------------------- */
+/* drivers                                                                   */
+/* ------------------------------------------------------------------------- */
+
+/* ref src/sdrrcv.c:505-532 */
+void orc_getbuff(const orc_ring_t *ring, uint64_t buffloc, int n, int dtype,
+                 signed char *out)
+{
+    uint64_t rb = (uint64_t)dtype * ring->ringlen;
+    uint64_t loc = ((uint64_t)dtype * buffloc) % rb;
+    int nb = dtype * n;
+    int nout = (int)((int64_t)(loc + (uint64_t)nb) - (int64_t)rb);
+    if (nout > 0) {
+        memcpy(out, ring->buff + loc, (size_t)(nb - nout));
+        memcpy(out + (nb - nout), ring->buff, (size_t)nout);
+    } else {
+        memcpy(out, ring->buff + loc, (size_t)nb);
+    }
+}
+
+/* ref src/sdrinit.c:583-657 with :385-394 (acq), :402-425 (loop constants),
+ * :432-480 (taps).  GLONASS FDMA offsets as :612-615. */
+int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
+                 double f_sf, double f_if, int corrn, int corrd, int corrp,
+                 const double *dllb, const double *pllb, const double *fllb)
+{
+    int i;
+    memset(ch, 0, sizeof(*ch));
+    ch->dtype = dtype;
+    ch->f_sf = f_sf;
+    ch->f_if = f_if;
+    ch->ti = 1 / f_sf;
+    if (orc_gencode(prn, ctype, ch->code, &ch->clen, &ch->crate) < 0) return -1;
+    ch->ci = ch->ti * ch->crate;
+    ch->ctime = ch->clen / ch->crate;
+    ch->nsamp = (int)(f_sf * ch->ctime);
+    ch->nsampchip = (int)(ch->nsamp / ch->clen);
+    if (ctype == ORC_CTYPE_G1) {
+        ch->f_cf = 1.60200E9 + 0.56250E6 * prn;
+        ch->foffset = 0.56250E6 * prn;
+    } else {
+        ch->f_cf = f_cf;
+        ch->foffset = 0.0;
+    }
+    ch->intg = 10;                       /* ACQINTG_*            */
+    ch->nfreq = 2 * (7000 / 200) + 1;    /* ACQHBAND / ACQSTEP   */
+    ch->nfft = 2 * ch->nsamp;
+    for (i = 0; i < ch->nfreq; i++)
+        ch->freq[i] = ch->f_if + ((i - (ch->nfreq - 1) / 2) * 200.0) + ch->foffset;
+    ch->corrn = corrn;
+    for (i = 0; i < corrn; i++) {
+        ch->corrp[i] = corrd * (i + 1);
+        if (ch->corrp[i] == corrp) { ch->ne = 2 * (i + 1) - 1; ch->nl = 2 * (i + 1); }
+    }
+    ch->loopms = (ctype == ORC_CTYPE_L1SBAS ? 2 : 10) * (int)(ch->ctime * 1000);
+    for (i = 0; i < 2; i++) {
+        ch->dllw2[i] = (dllb[i] / 0.53) * (dllb[i] / 0.53);
+        ch->dllaw[i] = 1.414 * (dllb[i] / 0.53);
+        ch->pllw2[i] = (pllb[i] / 0.53) * (pllb[i] / 0.53);
+        ch->pllaw[i] = 1.414 * (pllb[i] / 0.53);
+        ch->fllw[i]  = fllb[i] / 0.25;
+    }
+    return 0;
+}
+
+/* ref src/sdracq.c:14-62 */
+uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
+                            double *power, int mode, int *iters_done)
+{
+    signed char *data = (signed char *)malloc((size_t)2 * ch->nsamp * ch->dtype);
+    uint64_t buffloc = ring->wrpos - (uint64_t)(ch->intg + 1) * ch->nsamp;
+    int i;
+    for (i = 0; i < ch->intg; i++) {
+        orc_getbuff(ring, buffloc, 2 * ch->nsamp, ch->dtype, data);
+        buffloc += ch->nsamp;
+        orc_pcorrelator(data, ch->dtype, ch->ti, ch->nsamp, ch->freq, ch->nfreq,
+                        ch->crate, ch->nfft, ch->xcode, power, mode);
+        if (orc_checkacquisition(power, ch->nsamp, ch->nfreq, ch->nsampchip,
+                                 ch->ctime, ch->freq, &ch->acq)) {
+            ch->flagacq = 1;
+            break;
+        }
+    }
+    if (iters_done) *iters_done = (i < ch->intg) ? i + 1 : ch->intg;
+    if (ch->flagacq) {
+        buffloc += (uint64_t)(-(int64_t)(i + 1) * ch->nsamp + ch->acq.acqcodei);
+        ch->carrfreq = ch->acq.acqfreq;
+        ch->codefreq = ch->crate;
+    }
+    free(data);
+    return buffloc;
+}
+
+/* ref src/sdrtrk.c:15-54.  trk.QQ is handed to the correlator as its "II"
+ * and trk.II as its "QQ" (:42), and the old-value memcpy copies
+ * 1+2*corrn*sizeof(double) bytes (:35-36); both kept. */
+uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
+                         uint64_t buffloc, int mode)
+{
+    uint64_t bufflocnow = ring->wrpos - (uint64_t)ch->nsamp;
+    ch->flagtrk = 0;
+    if (bufflocnow > buffloc) {
+        signed char *data =
+            (signed char *)malloc((size_t)(ch->nsamp + 100) * ch->dtype);
+        ch->currnsamp = (int)((ch->clen - ch->remcode) / (ch->codefreq / ch->f_sf));
+        orc_getbuff(ring, buffloc, ch->currnsamp, ch->dtype, data);
+        memcpy(ch->oldI, ch->II, 1 + 2 * ch->corrn * sizeof(double));
+        memcpy(ch->oldQ, ch->QQ, 1 + 2 * ch->corrn * sizeof(double));
+        ch->oldremcode = ch->remcode;
+        ch->oldremcarr = ch->remcarr;
+        orc_correlator(data, ch->dtype, ch->ti, ch->currnsamp, ch->carrfreq,
+                       ch->oldremcarr, ch->codefreq, ch->oldremcode, ch->corrp,
+                       ch->corrn, ch->QQ, ch->II, &ch->remcode, &ch->remcarr,
+                       ch->code, ch->clen, mode);
+        ch->flagtrk = 1;
+        free(data);
+    }
+    return bufflocnow;
+}
+
+/* ref src/sdrtrk.c:64-76 */
+void orc_cumsumcorr(orc_chan_t *ch, int polarity)
+{
+    int i;
+    for (i = 0; i < 1 + 2 * ch->corrn; i++) {
+        ch->II[i] *= polarity;
+        ch->QQ[i] *= polarity;
+        ch->oldsumI[i] += ch->oldI[i];
+        ch->oldsumQ[i] += ch->oldQ[i];
+        ch->sumI[i] += ch->II[i];
+        ch->sumQ[i] += ch->QQ[i];
+    }
+}
+
+/* ref src/sdrtrk.c:77-86 */
+void orc_clearcumsumcorr(orc_chan_t *ch)
+{
+    int i;
+    for (i = 0; i < 1 + 2 * ch->corrn; i++)
+        ch->oldsumI[i] = ch->oldsumQ[i] = ch->sumI[i] = ch->sumQ[i] = 0;
+}
+
+/* ref src/sdrtrk.c:95-126 */
+void orc_pll(orc_chan_t *ch, int prm, double dt)
+{
+    double IP = ch->sumI[0], QP = ch->sumQ[0];
+    double oldIP = ch->oldsumI[0], oldQP = ch->oldsumQ[0];
+    double carrErr, freqErr, f1, f2;
+    if (IP > 0) carrErr = atan2(QP, IP) / ORC_PI;
+    else        carrErr = atan2(-QP, -IP) / ORC_PI;
+    f1 = (IP == 0)    ? ORC_PI / 2 : atan(QP / IP);
+    f2 = (oldIP == 0) ? ORC_PI / 2 : atan(oldQP / oldIP);
+    freqErr = f1 - f2;
+    if (freqErr >  ORC_PI / 2) freqErr =  ORC_PI - freqErr;
+    if (freqErr < -ORC_PI / 2) freqErr = -ORC_PI - freqErr;
+    ch->carrNco += ch->pllaw[prm] * (carrErr - ch->carrErr) +
+                   ch->pllw2[prm] * dt * carrErr + ch->fllw[prm] * dt * freqErr;
+    ch->carrfreq = ch->acq.acqfreq + ch->carrNco;
+    ch->carrErr = carrErr;
+    ch->freqErr = freqErr;
+}
+
+/* ref src/sdrtrk.c:135-150 */
+void orc_dll(orc_chan_t *ch, int prm, double dt)
+{
+    double IE = ch->sumI[ch->ne], IL = ch->sumI[ch->nl];
+    double QE = ch->sumQ[ch->ne], QL = ch->sumQ[ch->nl];
+    double codeErr = (sqrt(IE * IE + QE * QE) - sqrt(IL * IL + QL * QL)) /
+                     (sqrt(IE * IE + QE * QE) + sqrt(IL * IL + QL * QL));
+    ch->codeNco += ch->dllaw[prm] * (codeErr - ch->codeErr) +
+                   ch->dllw2[prm] * dt * codeErr;
+    ch->codefreq = ch->crate - ch->codeNco +
+                   (ch->carrfreq - ch->f_if - ch->foffset) / (ch->f_cf / ch->crate);
+    ch->codeErr = codeErr;
+}

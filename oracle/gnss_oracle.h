@@ -1,0 +1,164 @@
+/*
+ * gnss_oracle.h -- CPU restatement of the GNSS-SDRLIB acquisition + tracking
+ * correlation path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the timed CPU baseline.
+ * The product (libgnsscorr.so) never links, loads or calls anything in here.
+ *
+ * PARITY UNPINNED: the reference (mfkiwl/erlangnetwork-gnsslib-sdr) ships no
+ * tests, golden vectors or result fixtures for this path, and it cannot be
+ * compiled in this image (every .c file under src/ includes src/sdr.h, which includes
+ * fftw3.h, fec.h and libusb-1.0/libusb.h -- none of them installed, and the
+ * lib/fftw3 + lib/ka9q-fec submodule directories are empty).  This file is a
+ * line-cited restatement read off the reference sources; the only external
+ * known answers it is checked against are the IS-GPS-200 C/A "first 10 chips"
+ * octal table (tests/golden/ca_first10_octal.json) and numpy's FFT.
+ *
+ * Two flavours of the two NCOs are provided:
+ *   *_seq : literal restatement (phase/code offset advanced by repeated += in
+ *           fp64, exactly as the reference loops do);
+ *   *_cf  : the closed form the HIP kernels implement (phase_k =
+ *           fma(k, step, phase_0)); identical mathematics, differs from _seq
+ *           only through fp64 rounding of the running sum.
+ * GPU results are compared bit-exactly with _cf and to 1e-4 relative
+ * (north_star tolerance) with _seq.
+ */
+#ifndef GNSS_ORACLE_H
+#define GNSS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_CDIV    32
+#define ORC_CSCALE  (1.0/32.0)
+#define ORC_PI      3.1415926535897932
+#define ORC_DPI     (2.0*ORC_PI)
+
+#define ORC_CTYPE_L1CA   1
+#define ORC_CTYPE_G1     20
+#define ORC_CTYPE_L1SBAS 27
+
+/* ref src/sdrcode.c:101-154, :426-444, :523-539 */
+int orc_gencode(int prn, int ctype, short *code, int *len, double *crate);
+
+/* ref src/sdrcmn.c:633-669 (literal) and closed form */
+void   orc_carrier_lut(short *cost, short *sint);
+double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
+                       double freq, double phi0, short *I, short *Q);
+double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
+                      double freq, double phi0, short *I, short *Q);
+
+/* ref src/sdrcmn.c:608-621 (literal) and closed form */
+double orc_rescode_seq(const short *code, int len, double coff, int smax,
+                       double ci, int n, short *rcode);
+double orc_rescode_cf(const short *code, int len, double coff, int smax,
+                      double ci, int n, short *rcode);
+
+/* ref src/sdrcmn.c:687-722; mode 0 = seq NCOs, 1 = closed-form NCOs */
+void orc_correlator(const signed char *data, int dtype, double ti, int n,
+                    double freq, double phi0, double crate, double coff,
+                    const int *s, int ns, double *II, double *QQ,
+                    double *remc, double *remp, const short *code, int clen,
+                    int mode);
+
+/* ref src/sdrcmn.c:185-195 */
+void orc_cpxcpx(const short *I, const short *Q, double scale, int n,
+                float *cpx);
+/* unnormalised DFT of any length, sign -1 forward / +1 backward, float in/out
+ * (stands in for FFTW3f: ref src/sdrcmn.c:134-175) */
+void orc_fft(float *cpx, int n, int sign);
+/* ref src/sdrcmn.c:228-251 */
+void orc_cpxconv(float *cpxa, const float *cpxb, int m, int n, int flagsum,
+                 double *conv);
+/* ref src/sdrcmn.c:261-276 */
+void orc_cpxpspec(float *cpx, int n, int flagsum, double *pspec);
+/* ref src/sdrinit.c:645-655 : xcode = FFT_nfft(zero-padded resampled code) */
+void orc_codespectrum(const short *code, int clen, double ci, int nsamp,
+                      int nfft, float *xcode);
+/* ref src/sdrcmn.c:738-773; mode as orc_correlator */
+void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
+                     const double *freq, int nfreq, double crate, int m,
+                     const float *codex, double *P, int mode);
+/* time-domain evaluation of the same quantity (SURVEY 8a normative form):
+ * P[b][k] += |sum_j w[k+j] r[j]|^2/(32 m)^2, lags k in [k0,k1) only */
+void orc_pcorrelator_td(const signed char *data, int dtype, double ti, int n,
+                        const double *freq, int nfreq, int m,
+                        const short *code, int clen, double ci,
+                        int k0, int k1, double *P, int mode);
+
+/* ref src/sdrcmn.c:461-497, :574-578 */
+double orc_maxvd(const double *d, int n, int exinds, int exinde, int *ind);
+double orc_meanvd(const double *d, int n, int exinds, int exinde);
+
+typedef struct {
+    int    acqcodei;
+    int    freqi;
+    double acqfreq;
+    double cn0;
+    double peakr;
+    int    acquired;
+} orc_acqres_t;
+/* ref src/sdracq.c:71-95 */
+int orc_checkacquisition(const double *P, int nsamp, int nfreq, int nsampchip,
+                         double ctime, const double *freq, orc_acqres_t *res);
+
+/* IF sample ring as in ref src/sdrrcv.c:505-532 (file front end) */
+typedef struct {
+    const signed char *buff;   /* dtype*ringlen bytes                        */
+    uint64_t ringlen;          /* samples in the ring (MEMBUFFLEN*FILE_BUFFSIZE) */
+    uint64_t wrpos;            /* fendbuffsize*buffcnt: samples written so far */
+} orc_ring_t;
+void orc_getbuff(const orc_ring_t *ring, uint64_t buffloc, int n, int dtype,
+                 signed char *out);
+
+/* channel description + tracking state used by the driver restatements */
+#define ORC_MAXTAPS 33
+typedef struct {
+    /* constants (ref src/sdrinit.c:583-657) */
+    int    dtype, clen, nsamp, nsampchip;
+    double f_sf, f_if, foffset, f_cf, crate, ctime, ti, ci;
+    short  code[1023];
+    /* acquisition (ref src/sdr.h:344-356) */
+    int    intg, nfreq, nfft;
+    double freq[256];
+    const float *xcode;        /* nfft complex floats                        */
+    orc_acqres_t acq;
+    int    flagacq, flagtrk;
+    /* tracking (ref src/sdr.h:371-412) */
+    int    corrn, corrp[16], ne, nl, loopms;
+    double codefreq, carrfreq, remcode, remcarr, oldremcode, oldremcarr;
+    double codeNco, codeErr, carrNco, carrErr, freqErr;
+    double II[ORC_MAXTAPS], QQ[ORC_MAXTAPS], oldI[ORC_MAXTAPS],
+           oldQ[ORC_MAXTAPS], sumI[ORC_MAXTAPS], sumQ[ORC_MAXTAPS],
+           oldsumI[ORC_MAXTAPS], oldsumQ[ORC_MAXTAPS];
+    int    currnsamp;
+    /* loop parameters (ref src/sdrinit.c:402-425) */
+    double dllw2[2], dllaw[2], pllw2[2], pllaw[2], fllw[2];
+} orc_chan_t;
+
+/* ref src/sdrinit.c:583-657 (+ :385-394, :402-480); xcode left NULL */
+int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
+                 double f_sf, double f_if, int corrn, int corrd, int corrp,
+                 const double *dllb, const double *pllb, const double *fllb);
+/* ref src/sdracq.c:14-62 (no sleep, no printf); power = nsamp*nfreq zeroed
+ * doubles; returns buffloc */
+uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
+                            double *power, int mode, int *iters_done);
+/* ref src/sdrtrk.c:15-54 (without sdrnavigation); returns bufflocnow */
+uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
+                         uint64_t buffloc, int mode);
+/* ref src/sdrtrk.c:64-86 */
+void orc_cumsumcorr(orc_chan_t *ch, int polarity);
+void orc_clearcumsumcorr(orc_chan_t *ch);
+/* ref src/sdrtrk.c:95-150; prm = 0 (before nav sync) or 1 (after) */
+void orc_pll(orc_chan_t *ch, int prm, double dt);
+void orc_dll(orc_chan_t *ch, int prm, double dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

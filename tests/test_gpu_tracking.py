@@ -1,0 +1,140 @@
+"""HIP tracking correlators vs the CPU oracle (parity tests proper, -m gpu).
+
+Bar: bit-exact against the oracle's closed-form NCO variant (integer
+accumulators), and within 1e-4 relative (north_star tolerance) of the literal
+sequential-NCO restatement of the reference (ref src/sdrcmn.c:608-722)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F_SF = 16.368e6
+
+
+def _setup(gc, orc, engine, dtype, f_if, corrn, corrd, corrp, prns, nsamples, seed, buffloc0, ringlen=None,
+           amp=60):
+    rng = np.random.default_rng(seed)
+    shape = (nsamples, 2) if dtype == 2 else (nsamples,)
+    data = rng.integers(-amp, amp + 1, size=shape, dtype=np.int8)
+    # include the int8 extremes
+    data.reshape(-1)[:4] = [-128, 127, -128, 127]
+    ringlen = ringlen or nsamples
+    engine.ring_create(1, dtype, ringlen)
+    engine.ring_push_raw(1, data, nsamples)
+    chans = [gc.Channel(p, dtype=dtype, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp) for p in prns]
+    engine.set_channels(chans)
+    states, ochs = [], []
+    for i, c in enumerate(chans):
+        # channel 0 starts like a channel fresh out of acquisition (remcode = remcarr = 0,
+        # codefreq = crate: ref src/sdracq.c:54-55), the others mid-track.  A code phase that
+        # is an exact integer with a non-dyadic chip step is avoided: there the reference's
+        # own chip choice hinges on the rounding of its running fp64 sum.
+        st = dict(carrfreq=f_if + rng.uniform(-5000, 5000),
+                  codefreq=c.crate + (rng.uniform(-3, 3) if i else 0.0),
+                  remcode=rng.uniform(0.01, 0.99) if i else 0.0, remcarr=rng.uniform(0, 6.2) if i else 0.0,
+                  buffloc=buffloc0 + 1000 * i + (i % 3))
+        states.append(st)
+        o = orc.make_chan(c.prn, dtype=dtype, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
+        ochs.append(o)
+    engine.trk_set_state(states)
+    return data, chans, states, ochs
+
+
+def _oracle_run(orc, ochs, states, data, ringlen, wrpos, nepoch, mode):
+    ring = orc.make_ring(data, ringlen, wrpos)
+    L = orc.lib()
+    ntap = 1 + 2 * ochs[0].corrn
+    II = np.zeros((len(ochs), nepoch, ntap))
+    QQ = np.zeros_like(II)
+    ns = np.zeros((len(ochs), nepoch), np.int32)
+    fin = []
+    for i, (o, st) in enumerate(zip(ochs, states)):
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
+        buffloc = st["buffloc"]
+        for e in range(nepoch):
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc, mode)
+            assert o.flagtrk == 1
+            II[i, e] = np.ctypeslib.as_array(o.II)[:ntap]
+            QQ[i, e] = np.ctypeslib.as_array(o.QQ)[:ntap]
+            ns[i, e] = o.currnsamp
+            buffloc += o.currnsamp
+        fin.append(dict(remcode=o.remcode, remcarr=o.remcarr, buffloc=buffloc))
+    return II, QQ, ns, fin
+
+
+@pytest.mark.parametrize("dtype,f_if,corrn,corrd,corrp", [
+    (2, 0.0, 2, 3, 3),          # BASELINE config 3: int8 IQ, 5 taps
+    (1, 4.092e6, 6, 3, 6),      # frontend/iffile.ini: real IF, 13 taps
+    (2, 0.0, 1, 8, 8),          # plain E-P-L
+    (1, 4.092e6, 2, 3, 3),
+])
+def test_trk_batch_matches_oracle(gc, orc, engine, dtype, f_if, corrn, corrd, corrp):
+    nsamples = 16 * 8192
+    nepoch = 6
+    data, chans, states, ochs = _setup(gc, orc, engine, dtype, f_if, corrn, corrd, corrp,
+                                       prns=[1, 7, 13, 32], nsamples=nsamples, seed=11 + corrn,
+                                       buffloc0=5)
+    engine.trk_run(nepoch)
+    II, QQ, ns = engine.trk_fetch()
+    fin = engine.trk_get_state()
+    # closed-form oracle: bit exact
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=1)
+    assert np.array_equal(ns, ons)
+    assert np.array_equal(II, oII)
+    assert np.array_equal(QQ, oQQ)
+    for a, b in zip(fin, ofin):
+        assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
+    # literal (sequential NCO) oracle: north_star tolerance 1e-4 relative
+    sII, sQQ, sns, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=0)
+    assert np.array_equal(ns, sns)
+    assert rel_err(II, sII) <= 1e-4
+    assert rel_err(QQ, sQQ) <= 1e-4
+    # cumsumcorr over the batch (ref src/sdrtrk.c:64-76)
+    sI, sQ = engine.trk_fetch_sums()
+    assert np.array_equal(sI, II.sum(axis=1))
+    assert np.array_equal(sQ, QQ.sum(axis=1))
+
+
+def test_trk_ring_wrap(gc, orc, engine):
+    """A code period that straddles the end of the ring (ref src/sdrrcv.c:508-521)."""
+    ringlen = 16 * 4096
+    nsamples = ringlen
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[3, 9], nsamples=nsamples,
+                                       seed=5, buffloc0=ringlen - 9000, ringlen=ringlen)
+    # pretend the writer lapped the ring twice more: same bytes, write position two rings further
+    engine.ring_commit(1, 2 * ringlen)
+    for s in states:
+        s["buffloc"] += ringlen
+    engine.trk_set_state(states)
+    engine.trk_run(2)
+    II, QQ, ns = engine.trk_fetch()
+    oII, oQQ, ons, _ = _oracle_run(orc, ochs, states, data, ringlen, 3 * ringlen, 2, mode=1)
+    assert np.array_equal(ns, ons) and np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+
+
+def test_correlator_symbol(gc, orc):
+    """The reference-named correlator() (ref src/sdrcmn.c:687-722) through the C ABI."""
+    L = gc.lib()
+    rng = np.random.default_rng(3)
+    for dtype, freq in ((2, 1234.5), (1, 4.092e6 - 2200.0), (2, -3.9e6)):
+        n = 16369
+        data = rng.integers(-100, 101, size=n * dtype, dtype=np.int8)
+        code, crate = gc.gencode(5, gc.CTYPE_L1CA)
+        s = np.array([3, 6, 9], np.int32)
+        II, QQ = np.zeros(7), np.zeros(7)
+        remc, remp = C.c_double(), C.c_double()
+        code16 = code.astype(np.int16)
+        L.correlator(data.ctypes.data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s.ctypes.data, 3,
+                     II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code16.ctypes.data, 1023)
+        oII, oQQ, orc_c, orc_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s,
+                                                code16, 1)
+        assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+        assert remc.value == orc_c and remp.value == orc_p
+        sII, sQQ, src_c, src_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s,
+                                                code16, 0)
+        assert rel_err(II, sII) <= 1e-4 and rel_err(QQ, sQQ) <= 1e-4
+        assert abs(remc.value - src_c) <= 1e-6 and abs(remp.value - src_p) <= 1e-6
