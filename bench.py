@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the GNSS correlation hot path on MI355X.
+
+Contract (one JSON line on rank 0):
+  metric  "correlations/sec (1 ms coh) + x real-time, 32-SV L1CA @16.368 Msps"  (BASELINE.json)
+  step    one pass of the tracking hot path over one batch: 32 GPS L1CA channels x
+          `--epochs` code periods (1 ms coherent each), 5-tap E/P/L correlators with carrier
+          wipe-off, int8 IQ at 16.368 Msps (BASELINE configs[2]); planner + correlator +
+          cumsumcorr kernels, IF samples already resident in the HBM ring.
+  value   tap-correlations per second, whole job (all ranks); x_realtime = signal-ms processed per
+          wall-ms for the whole 32-SV set.
+  also    "acquisition": BASELINE configs[1] (32-SV cold search, 71 Doppler bins x 10 x 1 ms) timed
+          the same way in the same run; "roofline" for the dominant kernel (trk_corr) and
+          "rooflines" for the others; "cpu_baseline": the CPU oracle on the host cores.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling in channels -- every
+rank tracks its own 32 channels on the same IF stream; rank 0 owns the stream and each step's
+chunk is broadcast once over RCCL/xGMI into every rank's HBM ring (double buffered against the
+correlators).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+F_SF = 16.368e6
+NSAMP = 16368
+NCH = 32
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "correlations/sec (1 ms coh) + x real-time, 32-SV L1CA @16.368 Msps"
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_signal(gc, synth, nms, seed):
+    """nms milliseconds of int8 IQ with ~10 of PRN 1..32 present; cached in /tmp."""
+    cache = f"/tmp/gnsscorr_if_{nms}ms_{seed}.npy"
+    if os.path.exists(cache):
+        try:
+            return np.load(cache), synth.default_sats(list(range(1, 33)), seed=seed)
+        except Exception:
+            pass
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in range(1, 33)}
+    sats = synth.default_sats(list(range(1, 33)), seed=seed)
+    t0 = time.time()
+    data = synth.make_if(codes, nms * NSAMP, f_sf=F_SF, f_if=0.0, dtype=2, sats=sats, seed=seed)
+    log(f"synthetic IF: {nms} ms generated in {time.time() - t0:.1f} s")
+    try:
+        np.save(cache, data)
+    except Exception:
+        pass
+    return data, sats
+
+
+def channel_set(gc, rank):
+    """32 channels per rank: PRN 1..32 on rank 0 (bin/gnss-sdrcli.ini:5-9), the next C/A PRNs of the
+    210-entry table on the other ranks (weak scaling in channels)."""
+    prns = [((32 * rank + i) % 210) + 1 for i in range(NCH)]
+    return [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in prns]
+
+
+def cpu_baseline_tracking(orc, data, ringlen, chans, states, seconds_budget=12.0):
+    """The oracle's literal sdrtracking()/correlator() (one thread per channel like the reference's
+    sdrthread, ref src/sdrmain.c:144-149) on the host cores, bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    ncores = min(len(chans), os.cpu_count() or 1)
+    L = orc.lib()
+    ring = orc.make_ring(data, ringlen, ringlen)
+
+    def run(i, nepoch):
+        c, st = chans[i], states[i]
+        o = orc.make_chan(c.prn, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
+        b = st["buffloc"]
+        for _ in range(nepoch):
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), b, 0)
+            b += o.currnsamp
+        return nepoch
+
+    t0 = time.time()
+    run(0, 20)
+    per_call = (time.time() - t0) / 20
+    nepoch = int(max(20, min(2000, seconds_budget / (per_call * len(chans) / ncores))))
+    t0 = time.time()
+    with ThreadPoolExecutor(ncores) as ex:
+        list(ex.map(lambda i: run(i, nepoch), range(len(chans))))
+    dt = time.time() - t0
+    ntap = chans[0].ntap
+    return dict(value=len(chans) * nepoch * ntap / dt, unit="correlations/s", cores=ncores, kind="port",
+                sample=f"{len(chans)} channels x {nepoch} epochs x {ntap} taps, oracle literal-NCO correlator "
+                       f"(one thread per channel), {dt:.1f} s wall",
+                x_realtime=nepoch / dt / 1000.0)
+
+
+def cpu_baseline_acq(orc, data, ringlen, wrpos, chans, seconds_budget=12.0):
+    from concurrent.futures import ThreadPoolExecutor
+    ncores = min(len(chans), os.cpu_count() or 1)
+    L = orc.lib()
+    o0 = orc.make_chan(chans[0].prn, dtype=2, f_if=0.0)
+    n, nf = o0.nsamp, o0.nfreq
+    ring = orc.make_ring(data, ringlen, wrpos)
+    buf = np.zeros(2 * n * 2, np.int8)
+    L.orc_getbuff(C.byref(ring), wrpos - 11 * n, 2 * n, 2, buf.ctypes.data)
+
+    def run(i):
+        o = orc.make_chan(chans[i].prn, dtype=2, f_if=0.0)
+        xc = orc.codespectrum(o)
+        P = np.zeros(nf * n)
+        freq = np.ctypeslib.as_array(o.freq)[:nf].copy()
+        t = time.time()
+        L.orc_pcorrelator(buf.ctypes.data, 2, o.ti, n, freq.ctypes.data, nf, o.crate, o.nfft, xc.ctypes.data,
+                          P.ctypes.data, 0)
+        return time.time() - t
+
+    nsv = ncores            # one pcorrelator() call (71 bins, 1 iteration) per core
+    t0 = time.time()
+    with ThreadPoolExecutor(ncores) as ex:
+        list(ex.map(run, range(nsv)))
+    dt = time.time() - t0
+    return dict(value=nsv * nf / dt, unit="correlations/s", cores=ncores, kind="port",
+                sample=f"{nsv} SV x 1 iteration x {nf} bins, oracle pcorrelator (mixed-radix DFT length 32736 "
+                       f"standing in for FFTW3f, which is not installed), {dt:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--epochs", type=int, default=1000, help="code periods per channel per step")
+    ap.add_argument("--acq-steps", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-acq", action="store_true", help="skip the acquisition leg")
+    ap.add_argument("--seed", type=int, default=20240601)
+    args = ap.parse_args()
+
+    import torch
+    import gnsscorr_loader
+    gc = gnsscorr_loader.load()
+    import importlib
+    synth = importlib.import_module("erlangnetwork_gnsslib_sdr_amd.synth")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    E = args.epochs
+    # HBM ring = two chunks of E code periods; while one is correlated the next one lands in the
+    # other half.  Rank 0 owns the IF stream (one synthetic chunk, repeated).
+    chunk = E * NSAMP                               # samples; 2*chunk bytes is a multiple of 16
+    ringlen = 2 * chunk
+    if rank == 0:
+        data, sats = make_signal(gc, synth, E, args.seed)
+        host = np.concatenate([data, data], axis=0)
+    else:
+        host, sats = None, None
+
+    stream = torch.cuda.current_stream()
+    eng = gc.Engine(local_rank, stream=stream.cuda_stream)
+    ring_t = torch.zeros(ringlen * 2, dtype=torch.int8, device=dev)         # the HBM ring of this rank
+    eng.ring_create(1, 2, ringlen, ring_t.data_ptr())
+    if rank == 0:
+        ring_t.copy_(torch.from_numpy(host.reshape(-1)).to(dev))
+    if world > 1:
+        dist.broadcast(ring_t, src=0)
+    torch.cuda.synchronize()
+    eng.ring_commit(1, ringlen)
+
+    chans = channel_set(gc, rank)
+    eng.set_channels(chans)
+    rng = np.random.default_rng(args.seed + 17 * rank)
+    acq_hist = 11 * NSAMP
+    states0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)),
+                    remcode=float(rng.uniform(0.01, 0.99)), remcarr=float(rng.uniform(0, 6.2)),
+                    buffloc=int(rng.integers(0, NSAMP))) for c in chans]
+    eng.trk_set_state(states0)
+    ntap = chans[0].ntap
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- tracking leg (primary) -------------------------------------------
+    chunk_bytes = chunk * 2
+    pending = [None]
+
+    def step(i):
+        # The channels walk through the ring (state stays on the device); the IF chunk of the next
+        # step is broadcast from rank 0 into the idle half of every rank's ring while this step's
+        # half is correlated (one RCCL broadcast per epoch batch, ref SURVEY 8e).
+        if dist is not None:
+            if pending[0] is not None:
+                pending[0].wait()
+            nxt = (i + 1) % 2
+            pending[0] = dist.broadcast(ring_t[nxt * chunk_bytes:(nxt + 1) * chunk_bytes], src=0, async_op=True)
+        eng.trk_run(E)
+
+    for i in range(args.warmup):
+        step(i)
+    if pending[0] is not None:
+        pending[0].wait()
+        pending[0] = None
+    barrier()
+    eng.timing(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if pending[0] is not None:
+        pending[0].wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.timing(False)
+    k_ms, k_n = eng.timing_read("trk_corr")
+    p_ms, p_n = eng.timing_read("trk_plan")
+    s_ms, s_n = eng.timing_read("trk_sums")
+    dt_max = dt
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+
+    units = NCH * E * args.steps * world                  # channel-epochs, whole job
+    value = units * ntap / dt_max
+    x_rt = (E * args.steps / dt_max) / 1000.0             # epochs/s of the SV set / 1000 (per rank set)
+    bytes_unit = NSAMP * 2 + 1023 + 2 * ntap * 8          # IF window + code table + outputs
+    k_avg_ms = k_ms / max(k_n, 1)
+    ach = NCH * E * bytes_unit / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
+    roof = dict(kernel="trk_corr", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=ach / HBM_PEAK_GBS, traffic=None, launch_ms=k_avg_ms, launches=k_n,
+                algorithmic_bytes_per_launch=NCH * E * bytes_unit)
+    out = {
+        "metric": METRIC, "value": value, "unit": "correlations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int8 samples, int32 accumulators, fp64 NCO",
+        "data": "synthetic", "x_realtime": x_rt,
+        "config": {"workload": "BASELINE configs[2]: 32-SV GPS L1CA tracking, 5-tap E/P/L correlators "
+                               "(CORRN=2, CORRD=3), 1 ms coherent, 16.368 Msps int8 IQ, per GPU",
+                   "channels_per_gpu": NCH, "epochs_per_step": E, "taps": ntap,
+                   "if_broadcast": "RCCL broadcast of each step's IF chunk" if world > 1 else "none (1 GPU)"},
+        "roofline": roof,
+        "kernels_ms_per_step": {"trk_plan": p_ms / max(args.steps, 1), "trk_corr": k_ms / max(args.steps, 1),
+                                "trk_sums": s_ms / max(args.steps, 1)},
+    }
+
+    # ---- acquisition leg (configs[1]) --------------------------------------
+    if not args.no_acq:
+        wrpos = acq_hist + NSAMP // 3 + 100 * NSAMP if E > 120 else acq_hist + NSAMP // 3
+        for _ in range(2):
+            eng.acq_run(wrpos)
+        barrier()
+        eng.timing(True)
+        eng.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.acq_steps):
+            eng.acq_run(wrpos)
+        barrier()
+        adt = time.perf_counter() - t0
+        eng.timing(False)
+        if dist is not None:
+            t = torch.tensor([adt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            adt = float(t.item())
+        res = eng.acq_fetch()
+        nf, intg = chans[0].nfreq, chans[0].intg
+        useful = sum(r["iters"] for r in res) * nf
+        computed = NCH * nf * intg
+        c_ms, c_n = eng.timing_read("acq_corr")
+        f_ms, f_n = eng.timing_read("acq_fwd")
+        L = 32768
+        abytes = 8 * L + 8 * L + 16 * NSAMP           # SURVEY 8d per correlation
+        c_avg = c_ms / max(c_n, 1)
+        a_ach = computed * abytes / (c_avg * 1e-3) / 1e9 if c_n else 0.0
+        out["acquisition"] = {
+            "workload": "BASELINE configs[1]: 32-SV GPS L1CA cold acquisition, 71 Doppler bins x 10 x 1 ms, "
+                        "16.368 Msps int8 IQ, per GPU",
+            "value": computed * args.acq_steps * world / adt, "unit": "correlations/s (computed)",
+            "useful_correlations_per_s": useful * args.acq_steps * world / adt,
+            "ms_per_32sv_search": adt / args.acq_steps * 1e3,
+            "acquired": [c.prn for c, r in zip(chans, res) if r["flagacq"]],
+            "kernels_ms_per_search": {"acq_fwd": f_ms / max(f_n, 1), "acq_corr": c_avg},
+            "roofline": dict(kernel="acq_corr", bound="hbm", achieved=a_ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=a_ach / HBM_PEAK_GBS, traffic=None, launch_ms=c_avg, launches=c_n,
+                             algorithmic_bytes_per_launch=computed * abytes),
+        }
+
+    # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle as orc
+        flat = host
+        out["cpu_baseline"] = cpu_baseline_tracking(orc, flat, ringlen, chans, states0)
+        if not args.no_acq:
+            out["acquisition"]["cpu_baseline"] = cpu_baseline_acq(orc, flat, ringlen, acq_hist + NSAMP // 3, chans)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
