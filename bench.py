@@ -235,7 +235,7 @@ def main():
     eng.timing(False)
     k_ms, k_n = eng.timing_read("trk_corr")
     p_ms, p_n = eng.timing_read("trk_plan")
-    s_ms, s_n = eng.timing_read("trk_sums")
+    s_ms, s_n = eng.timing_read("trk_finish")
     dt_max = dt
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -262,7 +262,7 @@ def main():
                    "if_broadcast": "RCCL broadcast of each step's IF chunk" if world > 1 else "none (1 GPU)"},
         "roofline": roof,
         "kernels_ms_per_step": {"trk_plan": p_ms / max(args.steps, 1), "trk_corr": k_ms / max(args.steps, 1),
-                                "trk_sums": s_ms / max(args.steps, 1)},
+                                "trk_finish": s_ms / max(args.steps, 1)},
     }
 
     # ---- acquisition leg (configs[1]) --------------------------------------

@@ -73,6 +73,8 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     hipFree(ctx->dnsamp); ctx->dnsamp = nullptr;
     hipFree(ctx->dsumI);  ctx->dsumI = nullptr;
     hipFree(ctx->dsumQ);  ctx->dsumQ = nullptr;
+    hipFree(ctx->dpartial); ctx->dpartial = nullptr;
+    hipFree(ctx->dunit); ctx->dunit = nullptr;
     ctx->plan_cap = 0;
 }
 
@@ -330,11 +332,18 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipStreamSynchronize(ctx->stream));
     free_trk_buffers(ctx);
     GC_HIP(hipMalloc((void **)&ctx->dplan, sizeof(GcTrkPlan) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dunit, sizeof(GcTrkUnit) * units));
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dnsamp, sizeof(int) * units));
     GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dsumQ, sizeof(double) * ctx->nch * ctx->ntap));
+    ctx->nseg = 1;
+    for (int i = 0; i < ctx->nch; i++) {
+        const int s = gc_trk_nseg(ctx->hchan[i].dtype, ctx->max_n);
+        if (s > ctx->nseg) ctx->nseg = s;
+    }
+    GC_HIP(hipMalloc((void **)&ctx->dpartial, sizeof(int) * units * ctx->nseg * 2 * ctx->ntap));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -351,19 +360,24 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         rc = gc_launch_trk_plan(ctx->stream, ctx->dchan, ctx->dstate, ctx->dplan, ctx->nch, nepoch);
         if (rc) return rc;
     }
+    {
+        GcTimed t(ctx, "trk_expand");
+        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, ctx->dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch);
+        if (rc) return rc;
+    }
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
-        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dplan, ctx->dcorrI, ctx->dcorrQ, ctx->dnsamp,
-                                ctx->nch, nepoch, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit, ctx->dpartial, ctx->nch, nepoch, ctx->nseg,
+                                ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }
     {
-        GcTimed t(ctx, "trk_sums");
-        rc = gc_launch_trk_sums(ctx->stream, ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ, ctx->nch,
-                                nepoch, ctx->ntap);
+        GcTimed t(ctx, "trk_finish");
+        rc = gc_launch_trk_finish(ctx->stream, ctx->dpartial, ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ,
+                                  ctx->nch, nepoch, ctx->nseg, ctx->ntap);
         if (rc) return rc;
     }
     ctx->last_nepoch = nepoch;

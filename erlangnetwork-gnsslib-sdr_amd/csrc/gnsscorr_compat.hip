@@ -21,7 +21,9 @@ struct GcOnce {
     int8_t *code = nullptr;                          // 1024 chips
     GcChan *chan = nullptr;
     GcTrkPlan *plan = nullptr;
-    double *out = nullptr;                           // 2*GNSSCORR_MAXTAPS
+    GcTrkUnit *unit = nullptr;
+    double *out = nullptr;                           // 4*GNSSCORR_MAXTAPS: corrI, corrQ, sumI, sumQ
+    int *partial = nullptr;  int partial_cap = 0;    // nseg*2*ntap
 };
 static GcOnce g_once;
 
@@ -32,7 +34,8 @@ static int once_init(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&g_once.code, 1024));
     GC_HIP(hipMalloc((void **)&g_once.chan, sizeof(GcChan)));
     GC_HIP(hipMalloc((void **)&g_once.plan, sizeof(GcTrkPlan)));
-    GC_HIP(hipMalloc((void **)&g_once.out, sizeof(double) * 2 * GNSSCORR_MAXTAPS));
+    GC_HIP(hipMalloc((void **)&g_once.unit, sizeof(GcTrkUnit)));
+    GC_HIP(hipMalloc((void **)&g_once.out, sizeof(double) * 4 * GNSSCORR_MAXTAPS));
     return 0;
 }
 
@@ -82,8 +85,21 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
     GC_HIP(hipMemcpyAsync(g_once.code, chips, 1024, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(g_once.chan, &c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(g_once.plan, &p, sizeof(p), hipMemcpyHostToDevice, ctx->stream));
-    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.plan, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
-                            nullptr, 1, 1, c.ntap, dtype, c.ntap, n, c.smax);
+    const int nseg = gc_trk_nseg(dtype, n);
+    if (nseg * 2 * c.ntap > g_once.partial_cap) {
+        if (g_once.partial) hipFree(g_once.partial);
+        g_once.partial = nullptr; g_once.partial_cap = 0;
+        GC_HIP(hipMalloc((void **)&g_once.partial, sizeof(int) * nseg * 2 * c.ntap));
+        g_once.partial_cap = nseg * 2 * c.ntap;
+    }
+    rc = gc_launch_trk_expand(ctx->stream, g_once.chan, g_once.plan, g_once.unit, nullptr, 1, 1);
+    if (rc) return rc;
+    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.partial, 1, 1, nseg, c.ntap, dtype,
+                            c.ntap, n, c.smax);
+    if (rc) return rc;
+    rc = gc_launch_trk_finish(ctx->stream, g_once.partial, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
+                              g_once.out + 2 * GNSSCORR_MAXTAPS, g_once.out + 3 * GNSSCORR_MAXTAPS, 1, 1, nseg,
+                              c.ntap);
     if (rc) return rc;
     double host[2 * GNSSCORR_MAXTAPS];
     GC_HIP(hipMemcpyAsync(host, g_once.out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));

@@ -48,9 +48,12 @@ struct gnsscorr_ctx {
     // tracking
     GcTrkState *dstate = nullptr;
     GcTrkPlan *dplan = nullptr;
+    GcTrkUnit *dunit = nullptr;
     size_t plan_cap = 0;
     double *dcorrI = nullptr, *dcorrQ = nullptr, *dsumI = nullptr, *dsumQ = nullptr;
     int *dnsamp = nullptr;
+    int *dpartial = nullptr;       // [ch][epoch][segment][2*ntap] int32 partial sums
+    int nseg = 1;
     int last_nepoch = 0;
 
     // acquisition

@@ -42,6 +42,17 @@ struct GcTrkPlan {
     int      pad;
 };
 
+// Per-unit constants derived from the plan entry (one per channel and epoch).
+struct GcTrkUnit {
+    uint64_t a_al;      // 16-byte aligned ring byte offset of the period's first sample group
+    double   cs, ci;    // replica start phase (chips, in [0,len)) and chip step per sample
+    double   phis, ps;  // carrier phase at sample 0 and step per sample, in LUT steps
+    int      head;      // bytes between a_al and the first sample
+    int      n;         // currnsamp
+    int      G;         // 16-byte groups covering the period
+    int      nt;        // replica length n + 2*smax
+};
+
 // Row statistics of the accumulated power after one acquisition iteration.
 struct GcAcqRow {
     double rowmax;      // max over lags (first index on ties)
@@ -63,8 +74,10 @@ int gc_fail(int code, const char *fmt, ...);
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state,
                        GcTrkPlan *plan, int nch, int nepoch);
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, double *corrI,
-                       double *corrQ, int *nsamp_out, int nch, int nepoch, int ntap_stride,
-                       int dtype, int ntap, int max_n, int smax_max);
-int gc_launch_trk_sums(hipStream_t st, const double *corrI, const double *corrQ,
-                       double *sumI, double *sumQ, int nch, int nepoch, int ntap);
+int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
+                         int *nsamp_out, int nch, int nepoch);
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch,
+                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max);
+int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
+                         double *sumQ, int nch, int nepoch, int nseg, int ntap);
+int gc_trk_nseg(int dtype, int max_n);

@@ -18,6 +18,8 @@
 //              across the wavefront and the workgroup.  All sums are exact
 //              integers (|sum| < 2^31), scaled by 1/32 at the end like the
 //              reference's CSCALE.
+#include <cstdlib>
+
 #include "gnsscorr_internal.h"
 
 namespace {
@@ -82,12 +84,51 @@ __global__ void trk_plan_kernel(const GcChan *__restrict__ chan, GcTrkState *__r
 }
 
 // ---------------------------------------------------------------------------
+// per-unit constants
+// ---------------------------------------------------------------------------
+// One lane per (channel, epoch): everything the correlator workgroups would
+// otherwise each recompute (ring offset, NCO start values).
+__global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
+                                  GcTrkUnit *__restrict__ unit, int *__restrict__ nsamp_out, int nch,
+                                  int nepoch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nch * nepoch) return;
+    const GcChan &c = chan[i / nepoch];
+    const GcTrkPlan p = plan[i];
+    GcTrkUnit u;
+    const uint64_t a0 = (p.buffloc % c.ringlen) * (uint64_t)c.dtype;
+    u.a_al = a0 & ~(uint64_t)15;
+    u.head = (int)(a0 - u.a_al);
+    u.n = p.n;
+    u.G = (u.head + p.n * c.dtype + 15) >> 4;
+    u.nt = p.n + 2 * c.smax;
+    u.ci = __dmul_rn(c.ti, p.codefreq);
+    u.cs = gc_code_start(p.coff, c.smax, u.ci, c.clen);
+    // carrier NCO, ref src/sdrcmn.c:649-650
+    u.phis = __ddiv_rn(__dmul_rn(p.phi0, (double)GC_CDIV), GC_DPI);
+    u.ps = __dmul_rn(__dmul_rn(p.carrfreq, (double)GC_CDIV), c.ti);
+    unit[i] = u;
+    if (nsamp_out) nsamp_out[i] = p.n;
+}
+
+// ---------------------------------------------------------------------------
 // correlator
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum(int v)
+// sum over the wavefront, valid in lane 63 (row scans, then row broadcasts)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_add(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_sum63(int v)
+{
+    v = dpp_add<0x111, 0xF>(v);     // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);     // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);     // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);     // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);     // row_bcast:15
+    v = dpp_add<0x143, 0xC>(v);     // row_bcast:31
     return v;
 }
 
@@ -97,36 +138,53 @@ __constant__ signed char kCos32[32] = {32, 31, 30, 27, 23, 18, 12, 6, 0, -6, -12
 __constant__ signed char kSin32[32] = {0, 6, 12, 18, 23, 27, 30, 31, 32, 31, 30, 27, 23, 18, 12, 6,
                                        0, -6, -12, -18, -23, -27, -30, -31, -32, -31, -30, -27, -23, -18, -12, -6};
 
-template <int DTYPE, int NTAP>
+typedef short gc_s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(gc_s2, a), __builtin_bit_cast(gc_s2, b), c, false);
+}
+
+// Workgroup (seg, epoch, channel): correlates the 16-byte sample groups
+// [seg*256*NIT, (seg+1)*256*NIT) of one code period against every tap and
+// writes its 2*ntap int32 partial sums.
+//
+// LDS holds the period's resampled replica for this segment as one dword per
+// sample position, (chip(j), chip(j+1)) as two int16, so that the pair a tap
+// needs for samples (k, k+1) is a single aligned dword whatever the tap
+// offset: the taps then cost one v_dot2_i32_i16 per two samples and rail.
+template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict__ chan,
-                                                       const GcTrkPlan *__restrict__ plan,
-                                                       double *__restrict__ corrI,
-                                                       double *__restrict__ corrQ,
-                                                       int *__restrict__ nsamp_out, int nepoch,
-                                                       int ntap_stride, int ntap_lo, int max_n)
+                                                       const GcTrkUnit *__restrict__ unit,
+                                                       int *__restrict__ partial, int nepoch, int nseg,
+                                                       int ntap_stride, int ntap_lo, int max_n, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int e = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    constexpr int SPG = 16 / DTYPE;                 // samples per 16-byte group
+    constexpr int SEGG = 256 * NIT;                 // groups per segment
+    constexpr int SEGS = SEGG * SPG;                // samples per segment
+    const int seg = blockIdx.x, e = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x;
     const GcChan &c = chan[ch];
     const int ntap = c.ntap;
     // this instantiation serves channels with ntap in (ntap_lo, NTAP] and this dtype
     if (c.dtype != DTYPE || ntap > NTAP || ntap <= ntap_lo) return;
 
-    const GcTrkPlan p = plan[(size_t)ch * nepoch + e];
-    const int n = p.n, smax = c.smax, clen = c.clen;
-    const size_t obase = ((size_t)ch * nepoch + e) * ntap_stride;
-    if (tid == 0 && nsamp_out) nsamp_out[(size_t)ch * nepoch + e] = n;
-    if (n <= 0 || n > max_n) {          // outside the reference's (nsamp+100) scratch
-        if (tid < ntap) { corrI[obase + tid] = 0.0; corrQ[obase + tid] = 0.0; }
+    const GcTrkUnit u = unit[(size_t)ch * nepoch + e];
+    const int n = u.n, smax = c.smax, clen = c.clen, head = u.head, G = u.G;
+    int *pout = partial + (((size_t)ch * nepoch + e) * nseg + seg) * 2 * ntap_stride;
+    const int g0 = seg * SEGG;
+    // outside the reference's (nsamp+100) scratch, or nothing left for this segment
+    if (n <= 0 || n > max_n || g0 >= G) {
+        if (tid < 2 * ntap_stride) pout[tid] = 0;
         return;
     }
+    const int klo = (g0 * 16 - head) / DTYPE;       // first sample index of the segment (may be < 0)
 
     // LDS carve (all offsets multiples of 16)
     uint2 *lut = reinterpret_cast<uint2 *>(smem);                    // 32 x 8 B
     int *red = reinterpret_cast<int *>(smem + 256);                  // 4 x 2*NTAP ints
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
-    signed char *chips = reinterpret_cast<signed char *>(smem + 256 + RED_BYTES);  // clen (<= 1024)
-    signed char *rc = chips + 1024;                                  // nt + 2*GC_RCPAD
+    unsigned *rcp = reinterpret_cast<unsigned *>(smem + 256 + RED_BYTES);
 
     if (tid < 32) {
         const int cs_ = kCos32[tid], sn_ = kSin32[tid];
@@ -140,75 +198,127 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         }
         lut[tid] = v;
     }
-    for (int i = tid; i < clen; i += 256) chips[i] = c.code[i];
-    __syncthreads();
 
-    // resampled replica, ref src/sdrcmn.c:608-621 in closed form
-    const double ci = __dmul_rn(c.ti, p.codefreq);
-    const double cs = gc_code_start(p.coff, smax, ci, clen);
-    const int nt = n + 2 * smax;
-    for (int j = tid; j < nt + 2 * GC_RCPAD; j += 256) {
-        const int jj = j - GC_RCPAD;
-        signed char v = 0;
-        if (jj >= 0 && jj < nt) {
-            long long t = (long long)__fma_rn((double)jj, ci, cs);
-            while (t >= clen) t -= clen;
-            v = chips[(int)t];
+    // ---- resampled replica, ref src/sdrcmn.c:608-621 in closed form --------------------------
+    // position j of the replica (j = smax + k + tap offset) lives at rcp[j - klo]; chip index
+    // T(j) = trunc(fma(j, ci, cs)) is non-decreasing in j, so a 17-position task needs two
+    // evaluations plus a 4-step bisection when it holds one chip edge.
+    const double ci = u.ci, cs = u.cs;
+    const int nt = u.nt;
+    const int8_t *code = c.code;
+    const int npos = SEGS + 2 * smax + 1;           // positions this segment can touch
+    auto chipT = [&](int j) -> int { return (int)(long long)__fma_rn((double)j, ci, cs); };
+    auto chipS = [&](int T) -> int { while (T >= clen) T -= clen; return (int)code[T]; };
+    for (int q = tid; q * 16 < npos && !(ablate & 1); q += 256) {
+        const int j0 = klo + q * 16;
+        unsigned w[16];
+        if (j0 >= 0 && j0 + 16 < nt) {
+            const int T0 = chipT(j0), T1 = chipT(j0 + 16);
+            if (T1 - T0 <= 1) {
+                int lo = 0, hi = 16;                 // T(j0+lo) == T0, T(j0+hi) == T1
+                if (T1 != T0) {
+#pragma unroll
+                    for (int it = 0; it < 4; it++) {
+                        const int mid = (lo + hi) >> 1;
+                        if (chipT(j0 + mid) == T0) lo = mid; else hi = mid;
+                    }
+                } else {
+                    hi = 17;
+                }
+                const unsigned sa = (unsigned)chipS(T0) & 0xFFFFu, sb = (unsigned)chipS(T1) & 0xFFFFu;
+                const unsigned AA = sa | (sa << 16), AB = sa | (sb << 16), BB = sb | (sb << 16);
+#pragma unroll
+                for (int i = 0; i < 16; i++)         // pair (s(j0+i), s(j0+i+1)); first index holding sb is hi
+                    w[i] = (i + 1 < hi) ? AA : (i + 1 == hi ? AB : BB);
+            } else {
+                int prev = chipS(T0);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int nx = chipS(chipT(j0 + i + 1));
+                    w[i] = ((unsigned)prev & 0xFFFFu) | ((unsigned)nx << 16);
+                    prev = nx;
+                }
+            }
+        } else {                                    // task touches the ends of the replica
+            int prev = (j0 >= 0 && j0 < nt) ? chipS(chipT(j0)) : 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int j = j0 + i + 1;
+                const int nx = (j >= 0 && j < nt) ? chipS(chipT(j)) : 0;
+                w[i] = ((unsigned)prev & 0xFFFFu) | ((unsigned)nx << 16);
+                prev = nx;
+            }
         }
-        rc[j] = v;
+        uint4 *dst = reinterpret_cast<uint4 *>(rcp + q * 16);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
     }
     __syncthreads();
 
-    // carrier NCO, ref src/sdrcmn.c:649-650
-    const double phis = __ddiv_rn(__dmul_rn(p.phi0, (double)GC_CDIV), GC_DPI);
-    const double ps = __dmul_rn(__dmul_rn(p.carrfreq, (double)GC_CDIV), c.ti);
-
+    const double phis = u.phis, ps = u.ps;
     int accI[NTAP], accQ[NTAP], toff[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; t++) {
         accI[t] = 0;
         accQ[t] = 0;
-        toff[t] = GC_RCPAD + smax + (t < ntap ? c.tapoff[t] : 0);
+        toff[t] = smax + (t < ntap ? c.tapoff[t] : 0);
     }
-
-    const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
-    const uint64_t a0 = (p.buffloc % c.ringlen) * (uint64_t)DTYPE;
-    const uint64_t a_al = a0 & ~(uint64_t)15;
-    const int head = (int)(a0 - a_al);
-    const int G = (head + n * DTYPE + 15) >> 4;
-    constexpr int SPG = 16 / DTYPE;       // samples per 16-byte group
     const int8_t *ring = c.ring;
+    const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
 
-    for (int g = tid; g < G; g += 256) {
-        uint64_t addr = a_al + (uint64_t)g * 16;
+#pragma unroll 2
+    for (int it = 0; it < NIT; it++) {
+        const int gl = tid + 256 * it, g = g0 + gl;
+        if (g >= G || (ablate & 2)) break;
+        uint64_t addr = u.a_al + (uint64_t)g * 16;
         if (addr >= ringbytes) addr -= ringbytes;
-        const uint4 v = *reinterpret_cast<const uint4 *>(ring + addr);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        const int kb = (g * 16 - head) / DTYPE;   // exact: head is a multiple of DTYPE
+        uint4 v = *reinterpret_cast<const uint4 *>(ring + addr);
+        const int kb = (g * 16 - head) / DTYPE;     // exact: head is a multiple of DTYPE
+        const bool edge = kb < 0 || kb + SPG > n;
+        if (__ballot(edge) != 0ULL) {               // only the period's first / last wavefront
+            if (edge) {                             // blank the samples outside [0, n)
+                unsigned m[4];
 #pragma unroll
-        for (int i = 0; i < SPG; i++) {
-            const int k = kb + i;
-            const bool valid = (unsigned)k < (unsigned)n;
-            const double phi = __fma_rn((double)k, ps, phis);
-            const int idx = ((int)phi) & (GC_CDIV - 1);
-            const uint2 l = lut[idx];
-            int I, Q;
-            if (DTYPE == 2) {
-                const int sh = (i & 1) * 16;
-                const unsigned bI = valid ? (l.x << sh) : 0u, bQ = valid ? (l.y << sh) : 0u;
-                I = __builtin_amdgcn_sdot4((int)w[i >> 1], (int)bI, 0, false);
-                Q = __builtin_amdgcn_sdot4((int)w[i >> 1], (int)bQ, 0, false);
-            } else {
-                const int sh = (i & 3) * 8;
-                const unsigned bI = valid ? (l.x << sh) : 0u, bQ = valid ? (l.y << sh) : 0u;
-                I = __builtin_amdgcn_sdot4((int)w[i >> 2], (int)bI, 0, false);
-                Q = __builtin_amdgcn_sdot4((int)w[i >> 2], (int)bQ, 0, false);
+                for (int d = 0; d < 4; d++) {
+                    m[d] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int k = kb + (d * 4 + b) / DTYPE;
+                        if (k >= 0 && k < n) m[d] |= 0xFFu << (8 * b);
+                    }
+                }
+                v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
             }
+        }
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned ip[SPG / 2], qp[SPG / 2];
 #pragma unroll
-            for (int t = 0; t < NTAP; t++) {
-                const int pc = rc[toff[t] + k];
-                accI[t] = __mul24(pc, I) + accI[t];
-                accQ[t] = __mul24(pc, Q) + accQ[t];
+        for (int i = 0; i < SPG; i += 2) {
+            int I[2], Q[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int k = kb + i + s2;
+                const double phi = __fma_rn((double)k, ps, phis);
+                const uint2 l = lut[((int)phi) & (GC_CDIV - 1)];
+                const int sh = DTYPE == 2 ? ((i + s2) & 1) * 16 : ((i + s2) & 3) * 8;
+                const int wd = (int)w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
+                I[s2] = __builtin_amdgcn_sdot4(wd, (int)(l.x << sh), 0, false);
+                Q[s2] = __builtin_amdgcn_sdot4(wd, (int)(l.y << sh), 0, false);
+            }
+            ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
+            qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
+        }
+        const unsigned *rb = rcp + gl * SPG;
+#pragma unroll
+        for (int t = 0; t < NTAP; t++) {
+            const unsigned *rt = rb + toff[t];
+#pragma unroll
+            for (int j = 0; j < SPG / 2; j++) {
+                const unsigned cp = rt[2 * j];
+                accI[t] = dot2(ip[j], cp, accI[t]);
+                accQ[t] = dot2(qp[j], cp, accQ[t]);
             }
         }
     }
@@ -217,8 +327,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int t = 0; t < NTAP; t++) {
-        const int si = wave_sum(accI[t]), sq = wave_sum(accQ[t]);
-        if (lane == 0) {
+        const int si = wave_sum63(accI[t]), sq = wave_sum63(accQ[t]);
+        if (lane == 63) {
             red[wv * 2 * NTAP + t] = si;
             red[wv * 2 * NTAP + NTAP + t] = sq;
         }
@@ -231,59 +341,109 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
             si += red[w4 * 2 * NTAP + tid];
             sq += red[w4 * 2 * NTAP + NTAP + tid];
         }
-        corrI[obase + tid] = (double)si * (1.0 / 32.0);   // CSCALE, ref src/sdrcmn.c:716-719
-        corrQ[obase + tid] = (double)sq * (1.0 / 32.0);
+        pout[tid] = si;
+        pout[ntap_stride + tid] = sq;
     }
 }
 
-// cumsumcorr() over the batch, ref src/sdrtrk.c:64-76 (polarity +1: ocode is
-// all ones, ref src/sdrinit.c:520-521); sums in epoch order.
-__global__ void trk_sums_kernel(const double *__restrict__ corrI, const double *__restrict__ corrQ,
-                                double *__restrict__ sumI, double *__restrict__ sumQ, int nch,
-                                int nepoch, int ntap)
+// Sums the segment partials of every (channel, epoch) into the correlator
+// outputs (x CSCALE = 1/32, ref src/sdrcmn.c:716-719) and accumulates them over
+// the batch like cumsumcorr() (ref src/sdrtrk.c:64-76; polarity +1: ocode is
+// all ones, ref src/sdrinit.c:520-521).  All sums are exact integers.
+__global__ __launch_bounds__(256) void trk_finish_kernel(const int *__restrict__ partial,
+                                                         double *__restrict__ corrI,
+                                                         double *__restrict__ corrQ,
+                                                         double *__restrict__ sumI, double *__restrict__ sumQ,
+                                                         int nepoch, int nseg, int ntap)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nch * ntap) return;
-    const int ch = i / ntap, t = i % ntap;
-    double si = 0.0, sq = 0.0;
-    for (int e = 0; e < nepoch; e++) {
-        si += corrI[((size_t)ch * nepoch + e) * ntap + t];
-        sq += corrQ[((size_t)ch * nepoch + e) * ntap + t];
+    __shared__ long long acc[2 * GNSSCORR_MAXTAPS];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    if (tid < 2 * ntap) acc[tid] = 0;
+    __syncthreads();
+    long long loc[2 * GNSSCORR_MAXTAPS];
+    for (int t = 0; t < 2 * ntap; t++) loc[t] = 0;
+    for (int e = tid; e < nepoch; e += 256) {
+        const int *pp = partial + ((size_t)ch * nepoch + e) * nseg * 2 * ntap;
+        for (int t = 0; t < 2 * ntap; t++) {
+            int s = 0;
+            for (int g = 0; g < nseg; g++) s += pp[g * 2 * ntap + t];
+            const double v = (double)s * (1.0 / 32.0);
+            if (t < ntap) corrI[((size_t)ch * nepoch + e) * ntap + t] = v;
+            else corrQ[((size_t)ch * nepoch + e) * ntap + (t - ntap)] = v;
+            loc[t] += s;
+        }
     }
-    sumI[i] = si;
-    sumQ[i] = sq;
+    for (int t = 0; t < 2 * ntap; t++) atomicAdd((unsigned long long *)&acc[t], (unsigned long long)loc[t]);
+    __syncthreads();
+    if (tid < ntap) {
+        sumI[ch * ntap + tid] = (double)acc[tid] * (1.0 / 32.0);
+        sumQ[ch * ntap + tid] = (double)acc[ntap + tid] * (1.0 / 32.0);
+    }
 }
 
-template <int DTYPE, int NTAP>
-int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, double *corrI,
-                double *corrQ, int *nsamp_out, int nch, int nepoch, int ntap_stride, int ntap_lo,
-                int max_n, int smax_max)
+int g_trk_nit = 0;      // groups per lane per segment workgroup (2, 4 or 8); 0 = not yet chosen
+
+template <int DTYPE, int NTAP, int NIT>
+int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+                int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
 {
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
-    const size_t lds = 256 + RED_BYTES + 1024 + (((size_t)max_n + 2 * smax_max + 2 * GC_RCPAD + 15) & ~(size_t)15);
-    dim3 grid(nepoch, nch), block(256);
-    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP>), grid, block, lds, st, chan, plan, corrI, corrQ,
-                       nsamp_out, nepoch, ntap_stride, ntap_lo, max_n);
+    constexpr int SEGS = 256 * NIT * (16 / DTYPE);
+    const size_t npos = (((size_t)SEGS + 2 * smax_max + 1 + 15) / 16) * 16;
+    const int lds = (int)(256 + RED_BYTES + npos * 4);
+    static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
+    if (lds > 64 * 1024)
+        GC_HIP(hipFuncSetAttribute((const void *)trk_corr_kernel<DTYPE, NTAP, NIT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    dim3 grid(nseg, nepoch, nch), block(256);
+    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP, NIT>), grid, block, lds, st, chan, unit, partial, nepoch, nseg,
+                       ntap_stride, ntap_lo, max_n, ablate);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
+template <int DTYPE, int NTAP>
+int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+                    int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
+{
+    switch (g_trk_nit) {
+    default: return launch_corr<DTYPE, NTAP, 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    case 8: return launch_corr<DTYPE, NTAP, 8>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    case 4: return launch_corr<DTYPE, NTAP, 4>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    }
+}
+
 template <int DTYPE>
-int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, double *corrI,
-                     double *corrQ, int *nsamp_out, int nch, int nepoch, int ntap_stride, int ntap,
-                     int max_n, int smax_max)
+int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+                     int nseg, int ntap_stride, int ntap, int max_n, int smax_max)
 {
     // smallest instantiation that holds ntap accumulators; it serves (lo, NTAP]
-    if (ntap <= 3)  return launch_corr<DTYPE, 3>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 0, max_n, smax_max);
-    if (ntap <= 5)  return launch_corr<DTYPE, 5>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 3, max_n, smax_max);
-    if (ntap <= 7)  return launch_corr<DTYPE, 7>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 5, max_n, smax_max);
-    if (ntap <= 9)  return launch_corr<DTYPE, 9>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 7, max_n, smax_max);
-    if (ntap <= 13) return launch_corr<DTYPE, 13>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 9, max_n, smax_max);
-    if (ntap <= 21) return launch_corr<DTYPE, 21>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 13, max_n, smax_max);
-    return launch_corr<DTYPE, 33>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, 21, max_n, smax_max);
+#define GC_LC(N, LO) return launch_corr_nit<DTYPE, N>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, LO, max_n, smax_max)
+    if (ntap <= 3)  GC_LC(3, 0);
+    if (ntap <= 5)  GC_LC(5, 3);
+    if (ntap <= 7)  GC_LC(7, 5);
+    if (ntap <= 13) GC_LC(13, 7);
+    if (ntap <= 21) GC_LC(21, 13);
+    GC_LC(33, 21);
+#undef GC_LC
+}
+
+void trk_pick_nit()
+{
+    if (g_trk_nit) return;
+    const char *e = getenv("GNSSCORR_TRK_NIT");
+    g_trk_nit = e ? atoi(e) : 2;
+    if (g_trk_nit != 2 && g_trk_nit != 4 && g_trk_nit != 8) g_trk_nit = 2;
 }
 
 }  // namespace
+
+int gc_trk_nseg(int dtype, int max_n)
+{
+    trk_pick_nit();
+    const int groups = (15 + max_n * dtype + 15) / 16 + 1;
+    return (groups + 256 * g_trk_nit - 1) / (256 * g_trk_nit);
+}
 
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state, GcTrkPlan *plan,
                        int nch, int nepoch)
@@ -294,25 +454,36 @@ int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state, Gc
     return 0;
 }
 
-// One launch serves every channel whose (dtype, tap bucket) matches; callers
-// invoke it once per distinct (dtype, ntap) present in the channel set.
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, double *corrI,
-                       double *corrQ, int *nsamp_out, int nch, int nepoch, int ntap_stride,
-                       int dtype, int ntap, int max_n, int smax_max)
+int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
+                         int *nsamp_out, int nch, int nepoch)
 {
+    const int total = nch * nepoch;
+    hipLaunchKernelGGL(trk_expand_kernel, dim3((total + 255) / 256), dim3(256), 0, st, chan, plan, unit, nsamp_out,
+                       nch, nepoch);
+    GC_HIP(hipGetLastError());
+    return 0;
+}
+
+// One launch serves every channel whose (dtype, tap bucket) matches; callers
+// invoke it once per distinct dtype present in the channel set.
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch,
+                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max)
+{
+    trk_pick_nit();
+    if (nepoch > 65535 || nch > 65535) return gc_fail(GNSSCORR_EINVAL, "trk_corr: at most 65535 epochs per batch");
+    if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_corr: tap offset %d samples (<= 64 supported)", smax_max);
     if (dtype == 2)
-        return launch_corr_taps<2>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     if (dtype == 1)
-        return launch_corr_taps<1>(st, chan, plan, corrI, corrQ, nsamp_out, nch, nepoch, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<1>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     return gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
 }
 
-int gc_launch_trk_sums(hipStream_t st, const double *corrI, const double *corrQ, double *sumI,
-                       double *sumQ, int nch, int nepoch, int ntap)
+int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
+                         double *sumQ, int nch, int nepoch, int nseg, int ntap)
 {
-    const int total = nch * ntap;
-    hipLaunchKernelGGL(trk_sums_kernel, dim3((total + 127) / 128), dim3(128), 0, st, corrI, corrQ, sumI,
-                       sumQ, nch, nepoch, ntap);
+    hipLaunchKernelGGL(trk_finish_kernel, dim3(nch), dim3(256), 0, st, partial, corrI, corrQ, sumI, sumQ, nepoch,
+                       nseg, ntap);
     GC_HIP(hipGetLastError());
     return 0;
 }
