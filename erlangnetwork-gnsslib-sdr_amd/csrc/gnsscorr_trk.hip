@@ -25,8 +25,8 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// closed-form NCO chain (must stay operation-for-operation identical to
-// oracle/gnss_oracle.c: orc_mixcarr_cf / orc_rescode_cf / orc_sdrtracking)
+// closed-form NCO chain (the test-side CPU checker restates these operations
+// one for one; any change here changes the normative closed form)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double gc_carrier_rem(double phi0, double freq, double ti, int n)
 {

@@ -53,6 +53,7 @@ def lib():
     L = C.CDLL(LIB)
     d, i, vp = C.c_double, C.c_int, C.c_void_p
     L.orc_gencode.argtypes = [i, i, vp, C.POINTER(i), C.POINTER(d)]
+    L.orc_carrier_lut.argtypes = [vp, vp]
     for f in (L.orc_mixcarr_seq, L.orc_mixcarr_cf):
         f.restype = d
         f.argtypes = [vp, i, d, i, d, d, vp, vp]

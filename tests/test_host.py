@@ -1,0 +1,137 @@
+"""Host C side of the boundary (no GPU needed): INI surface, code generation,
+channel set-up, loop filters -- product (libgnsscorr.so, host C) against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _write_inis(tmp_path, rcv_extra=""):
+    fe = tmp_path / "fe.ini"
+    dat = tmp_path / "if.dat"
+    dat.write_bytes(b"\0" * 64)
+    fe.write_text(open(os.path.join(HERE, "golden", "frontend_file.ini")).read().replace("@FILE1@", str(dat)))
+    rcv = tmp_path / "gnss-sdrcli.ini"
+    rcv.write_text(open(os.path.join(HERE, "golden", "gnss-sdrcli.ini")).read().replace("@FENDCONF@", str(fe)) + rcv_extra)
+    return rcv, fe, dat
+
+
+def test_readinifile_keys_and_quirks(gc, tmp_path):
+    """Same keys / parsing rules as ref src/sdrinit.c:17-46,106-211."""
+    rcv, fe, dat = _write_inis(tmp_path)
+    ini = gc.SdrIni()
+    assert gc.lib().readinifile_at(C.byref(ini), str(rcv).encode()) == 0
+    assert ini.fend == 10 and ini.useif1 == 1 and ini.useif2 == 0
+    assert ini.file1.decode() == str(dat)
+    assert (ini.f_cf[0], ini.f_sf[0], ini.f_if[0], ini.dtype[0]) == (1575.42e6, 16.368e6, 4.092e6, 1)
+    assert (ini.trkcorrn, ini.trkcorrd, ini.trkcorrp) == (6, 3, 6)
+    assert list(ini.trkdllb) == [5.0, 1.0] and list(ini.trkpllb) == [30.0, 10.0] and list(ini.trkfllb) == [200.0, 50.0]
+    assert ini.nch == 4 and list(ini.prn)[:4] == [1, 2, 3, 120] and list(ini.ctype)[:4] == [1, 1, 1, 27]
+    assert ini.nchL1 == 3 and ini.log == 1 and ini.outms == 400 and ini.rtcmport == 9999
+    assert gc.lib().chk_initvalue(C.byref(ini)) == 0
+    # ';' starts a comment; the first match in the section wins; keys are right-trimmed
+    fe.write_text(fe.read_text().replace("CORRN    =6", "CORRN\t =4 ;was 6\nCORRN    =9"))
+    ini2 = gc.SdrIni()
+    assert gc.lib().readinifile_at(C.byref(ini2), str(rcv).encode()) == 0
+    assert ini2.trkcorrn == 4
+
+
+def test_readinifile_errors(gc, tmp_path, capfd):
+    ini = gc.SdrIni()
+    assert gc.lib().readinifile_at(C.byref(ini), str(tmp_path / "nope.ini").encode()) == -1
+    rcv, fe, dat = _write_inis(tmp_path)
+    fe.write_text(fe.read_text().replace("TYPE     =FILE", "TYPE     =FOO"))
+    assert gc.lib().readinifile_at(C.byref(ini), str(rcv).encode()) == -1
+    rcv.write_text(rcv.read_text().replace("NCH      =  4", "NCH      =  0"))
+    fe.write_text(fe.read_text().replace("TYPE     =FOO", "TYPE     =FILE"))
+    assert gc.lib().readinifile_at(C.byref(ini), str(rcv).encode()) == -1
+    C.CDLL(None).fflush(None)          # the library prints through C stdio
+    out = capfd.readouterr().out
+    assert "doesn't exist" in out and "wrong frontend type: FOO" in out and "wrong inifile value NCH=0" in out
+
+
+def test_gencode_product_vs_oracle_and_known_answers(gc, orc):
+    kat = json.load(open(os.path.join(HERE, "golden", "ca_first10_octal.json")))["first10_octal"]
+    for prn in list(range(1, 38)) + [120, 138, 193, 210]:
+        a, cra = gc.gencode(prn, gc.CTYPE_L1SBAS if prn >= 120 else gc.CTYPE_L1CA)
+        b, crb = orc.gencode(prn, 1)
+        assert np.array_equal(a, b) and cra == crb
+        if str(prn) in kat:
+            bits = "".join("1" if c == 1 else "0" for c in a[:10])
+            assert format(int(bits, 2), "o") == kat[str(prn)]
+    a, cr = gc.gencode(3, gc.CTYPE_G1)
+    b, _ = orc.gencode(3, 20)
+    assert np.array_equal(a, b) and cr == 0.511e6
+
+
+def test_initsdrch_matches_reference_shapes(gc, orc):
+    """n = 16368, nsampchip = 16, nfft = 32736, nfreq = 71, +-7 kHz / 200 Hz grid."""
+    L = gc.lib()
+    ini = gc.sdrini()
+    ini.trkcorrn, ini.trkcorrd, ini.trkcorrp = 6, 3, 6
+    ini.trkdllb[0], ini.trkdllb[1] = 5.0, 1.0
+    ini.trkpllb[0], ini.trkpllb[1] = 30.0, 10.0
+    ini.trkfllb[0], ini.trkfllb[1] = 200.0, 50.0
+    sdr = gc.SdrCh()
+    assert L.initsdrch(1, gc.SYS_GPS, 7, gc.CTYPE_L1CA, 1, 1, 1575.42e6, 16.368e6, 4.092e6, C.byref(sdr)) == 0
+    assert (sdr.nsamp, sdr.nsampchip, sdr.clen, sdr.acq.nfft, sdr.acq.nfreq, sdr.acq.intg) == (16368, 16, 1023, 32736, 71, 10)
+    assert sdr.satstr == b"G07" and sdr.sat == 7 and sdr.ci == 0.0625 and sdr.ctime == 1e-3
+    freq = np.ctypeslib.as_array(sdr.acq.freq, shape=(71,))
+    assert freq[0] == 4.092e6 - 7000 and freq[35] == 4.092e6 and freq[70] == 4.092e6 + 7000
+    assert (sdr.trk.corrn, sdr.trk.ne, sdr.trk.nl, sdr.trk.loopms) == (6, 3, 4, 10)
+    assert list(np.ctypeslib.as_array(sdr.trk.corrp, shape=(6,))) == [3, 6, 9, 12, 15, 18]
+    o = orc.make_chan(7, dtype=1, f_if=4.092e6, corrn=6, corrd=3, corrp=6)
+    assert sdr.trk.prm1.pllw2 == o.pllw2[0] and sdr.trk.prm2.dllaw == o.dllaw[1] and sdr.trk.prm1.fllw == o.fllw[0]
+    assert np.array_equal(np.ctypeslib.as_array(sdr.code, shape=(1023,)), np.ctypeslib.as_array(o.code))
+    # python mirror agrees with the C initsdrch
+    ch = gc.Channel(7, dtype=1, f_if=4.092e6, corrn=6, corrd=3, corrp=6)
+    assert (ch.nsamp, ch.nsampchip, ch.nfreq, ch.nfft, ch.ne, ch.nl) == (16368, 16, 71, 32736, 3, 4)
+    assert np.array_equal(ch.freq, freq)
+    L.freesdrch(C.byref(sdr))
+    # GLONASS FDMA offsets (ref src/sdrinit.c:612-615); SBAS satellite numbering
+    g = gc.SdrCh()
+    assert L.initsdrch(2, gc.SYS_GLO, -3, gc.CTYPE_G1, 2, 2, 1602e6, 20e6, 0.0, C.byref(g)) == 0
+    assert g.satstr == b"R-3" and g.foffset == -3 * 0.5625e6 and g.clen == 511 and g.nsamp == 20000
+    L.freesdrch(C.byref(g))
+    s = gc.SdrCh()
+    assert L.initsdrch(3, gc.SYS_SBS, 120, gc.CTYPE_L1SBAS, 1, 1, 1575.42e6, 16.368e6, 4.092e6, C.byref(s)) == 0
+    assert s.satstr == b"120" and s.sat == 33 and s.trk.loopms == 2
+    L.freesdrch(C.byref(s))
+
+
+def test_loop_filters_product_vs_oracle(gc, orc):
+    L = gc.lib()
+    ini = gc.sdrini()
+    ini.trkcorrn, ini.trkcorrd, ini.trkcorrp = 2, 3, 3
+    sdr = gc.SdrCh()
+    assert L.initsdrch(1, gc.SYS_GPS, 1, gc.CTYPE_L1CA, 2, 1, 1575.42e6, 16.368e6, 0.0, C.byref(sdr)) == 0
+    o = orc.make_chan(1, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+    rng = np.random.default_rng(0)
+    sdr.acq.acqfreq = o.acq.acqfreq = 1400.0
+    sdr.trk.carrfreq = o.carrfreq = 1400.0
+    sdr.trk.codefreq = o.codefreq = o.crate
+    for step in range(20):
+        vals = rng.uniform(-4000, 4000, size=(4, 5))
+        for i in range(5):
+            sdr.trk.II[i] = o.II[i] = vals[0, i]
+            sdr.trk.QQ[i] = o.QQ[i] = vals[1, i]
+            sdr.trk.oldI[i] = o.oldI[i] = vals[2, i]
+            sdr.trk.oldQ[i] = o.oldQ[i] = vals[3, i]
+        L.cumsumcorr(C.byref(sdr.trk), 1)
+        orc.lib().orc_cumsumcorr(C.byref(o), 1)
+        prm = sdr.trk.prm1 if step < 10 else sdr.trk.prm2
+        dt = 1e-3 if step < 10 else 1e-2
+        L.pll(C.byref(sdr), C.byref(prm), dt)
+        L.dll(C.byref(sdr), C.byref(prm), dt)
+        orc.lib().orc_pll(C.byref(o), 0 if step < 10 else 1, dt)
+        orc.lib().orc_dll(C.byref(o), 0 if step < 10 else 1, dt)
+        assert sdr.trk.carrfreq == o.carrfreq and sdr.trk.codefreq == o.codefreq
+        assert sdr.trk.carrNco == o.carrNco and sdr.trk.codeErr == o.codeErr and sdr.trk.freqErr == o.freqErr
+        if step % 3 == 2:
+            L.clearcumsumcorr(C.byref(sdr.trk))
+            orc.lib().orc_clearcumsumcorr(C.byref(o))
+    L.freesdrch(C.byref(sdr))
