@@ -200,6 +200,8 @@ def lib():
     _sig("pll", None, [C.POINTER(SdrCh), C.POINTER(SdrTrkPrm), C.c_double])
     _sig("dll", None, [C.POINTER(SdrCh), C.POINTER(SdrTrkPrm), C.c_double])
     _sig("readinifile_at", _KEEP, [C.POINTER(SdrIni), C.c_char_p])
+    _sig("rcvinit_file", _KEEP, [C.POINTER(SdrIni)])
+    _sig("file_pushtomembuf", None, [])
     _sig("chk_initvalue", _KEEP, [C.POINTER(SdrIni)])
     _sig("cpxpspec", None, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig("cpxfft", None, [C.c_void_p, C.c_void_p, C.c_int])

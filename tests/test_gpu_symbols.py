@@ -1,0 +1,199 @@
+"""The reference-named per-call symbols of libgnsscorr.so (include/sdr_compat.h) on the GPU,
+against the oracle.  These are the drop-in replacements a maintainer links instead of
+src/sdracq.c, src/sdrtrk.c and the DSP helpers of src/sdrcmn.c."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TI = 1 / 16.368e6
+
+
+def test_mixcarr_rescode_cpxcpx(gc, orc):
+    L, O = gc.lib(), orc.lib()
+    rng = np.random.default_rng(0)
+    for dtype, freq, phi0 in ((2, 1234.5, 0.4), (1, 4.092e6 - 700.0, 0.0), (2, -3.9e6, 2.0)):
+        n = 5000
+        data = rng.integers(-128, 128, size=n * dtype, dtype=np.int8)
+        I, Q, oI, oQ = (np.zeros(n, np.int16) for _ in range(4))
+        r = L.mixcarr(data.ctypes.data, dtype, TI, n, freq, phi0, I.ctypes.data, Q.ctypes.data)
+        ro = O.orc_mixcarr_cf(data.ctypes.data, dtype, TI, n, freq, phi0, oI.ctypes.data, oQ.ctypes.data)
+        assert np.array_equal(I, oI) and np.array_equal(Q, oQ) and r == ro
+    code, crate = orc.gencode(3, 1)
+    for coff, smax, dc in ((0.0, 0, 0.0), (100.25, 6, 1.5), (1022.9, 18, -2.0)):
+        n = 16368
+        a, b = np.zeros(n + 2 * smax, np.int16), np.zeros(n + 2 * smax, np.int16)
+        ci = TI * (crate + dc)
+        r = L.rescode(code.ctypes.data, 1023, coff, smax, ci, n, a.ctypes.data)
+        ro = O.orc_rescode_cf(code.ctypes.data, 1023, coff, smax, ci, n, b.ctypes.data)
+        assert np.array_equal(a, b) and r == ro
+    I = rng.integers(-8000, 8000, size=1000).astype(np.int16)
+    Q = rng.integers(-8000, 8000, size=1000).astype(np.int16)
+    x, xo = np.zeros(2000, np.float32), np.zeros(2000, np.float32)
+    L.cpxcpx(I.ctypes.data, Q.ctypes.data, (1 / 32) / 32736, 1000, x.ctypes.data)
+    O.orc_cpxcpx(I.ctypes.data, Q.ctypes.data, (1 / 32) / 32736, 1000, xo.ctypes.data)
+    assert np.array_equal(x, xo)
+    L.cpxcpx(I.ctypes.data, None, 1.0, 1000, x.ctypes.data)
+    assert np.all(x[1::2] == 0) and np.array_equal(x[0::2], I.astype(np.float32))
+
+
+@pytest.mark.parametrize("n", [1000, 4092, 16384, 32736, 32768])
+def test_cpxfft_cpxpspec_any_length(gc, orc, n):
+    L = gc.lib()
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128))
+    y = x.copy()
+    L.cpxfft(None, y.ctypes.data, n)
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-6
+    z = y.copy()
+    L.cpxifft(None, z.ctypes.data, n)
+    assert np.abs(z / n - x).max() < 2e-5
+    ps = np.full(n, 1.5)
+    xx = x.copy()
+    L.cpxpspec(None, xx.ctypes.data, n, 1, ps.ctypes.data)           # flagsum: accumulates
+    assert rel_err(ps - 1.5, np.abs(ref) ** 2) < 1e-5
+    xx = x.copy()
+    L.cpxpspec(None, xx.ctypes.data, n, 0, ps.ctypes.data)
+    assert rel_err(ps, np.abs(ref) ** 2) < 1e-5
+
+
+def test_cpxconv_and_pcorrelator_reference_length(gc, orc):
+    """m = 2*nsamp = 32736 exactly as the reference calls them (ref src/sdrcmn.c:738-773)."""
+    L, O = gc.lib(), orc.lib()
+    rng = np.random.default_rng(1)
+    o = orc.make_chan(6, dtype=2, f_if=0.0)
+    n, m = o.nsamp, o.nfft
+    xc = orc.codespectrum(o)
+    data = rng.integers(-60, 61, size=2 * n * 2, dtype=np.int8)
+    freq = np.array([-3000.0, 200.0, 5200.0])
+    P = np.full(3 * n, 0.25)
+    Po = P.copy()
+    L.pcorrelator(data.ctypes.data, 2, o.ti, n, freq.ctypes.data, 3, o.crate, m, xc.ctypes.data, P.ctypes.data)
+    O.orc_pcorrelator(data.ctypes.data, 2, o.ti, n, freq.ctypes.data, 3, o.crate, m, xc.ctypes.data,
+                      Po.ctypes.data, 1)
+    assert rel_err(P, Po) < 1e-4
+    a = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    b = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    a2, conv, convo = a.copy(), np.zeros(n), np.zeros(n)
+    L.cpxconv(None, None, a.ctypes.data, b.ctypes.data, m, n, 0, conv.ctypes.data)
+    O.orc_cpxconv(a2.ctypes.data, b.ctypes.data, m, n, 0, convo.ctypes.data)
+    assert rel_err(conv, convo) < 1e-4
+    assert np.abs(a - a2).max() / np.abs(a2).max() < 1e-5      # cpxa holds the inverse transform afterwards
+
+
+def test_maxvd_meanvd_checkacquisition(gc, orc):
+    L, O = gc.lib(), orc.lib()
+    rng = np.random.default_rng(2)
+    d = rng.uniform(0, 1, 16368)
+    d[0] = 2.0
+    d[4000] = d[9000] = 1.7
+    for exs, exe in ((-1, -1), (0, 40), (16300, 30), (3990, 4010)):
+        i1, i2 = C.c_int(), C.c_int()
+        assert L.maxvd(d.ctypes.data, len(d), exs, exe, C.byref(i1)) == O.orc_maxvd(d.ctypes.data, len(d), exs, exe, C.byref(i2))
+        assert i1.value == i2.value
+        assert L.meanvd(d.ctypes.data, len(d), exs, exe) == pytest.approx(O.orc_meanvd(d.ctypes.data, len(d), exs, exe), rel=1e-12)
+    ini = gc.sdrini()
+    ini.trkcorrn, ini.trkcorrd, ini.trkcorrp = 2, 3, 3
+    sdr = gc.SdrCh()
+    assert L.initsdrch(1, gc.SYS_GPS, 5, gc.CTYPE_L1CA, 2, 1, 1575.42e6, 16.368e6, 0.0, C.byref(sdr)) == 0
+    P = rng.uniform(0.5, 1.0, 71 * 16368)
+    P[40 * 16368 + 7] = 30.0
+    P[40 * 16368 + 9000] = 6.0
+    got = L.checkacquisition(P.ctypes.data, C.byref(sdr))
+    res = orc.AcqRes()
+    freq = np.ctypeslib.as_array(sdr.acq.freq, shape=(71,)).copy()
+    want = O.orc_checkacquisition(P.ctypes.data, 16368, 71, 16, 1e-3, freq.ctypes.data, C.byref(res))
+    assert got == want == 1
+    assert (sdr.acq.acqcodei, sdr.acq.freqi, sdr.acq.acqfreq) == (res.acqcodei, res.freqi, res.acqfreq)
+    assert sdr.acq.peakr == pytest.approx(res.peakr, rel=1e-12) and sdr.acq.cn0 == pytest.approx(res.cn0, rel=1e-12)
+    L.freesdrch(C.byref(sdr))
+
+
+def test_sdracquisition_then_sdrtracking_like_sdrthread(gc, orc, synth, tmp_path):
+    """The reference's channel loop (ref src/sdrmain.c:247-316) on the drop-in symbols: file front end ->
+    ring -> sdracquisition -> sdrtracking + cumsumcorr + pll/dll, against the oracle doing the same."""
+    os.environ["GNSSCORR_ACQSLEEP_MS"] = "0"
+    L, O = gc.lib(), orc.lib()
+    prn = 14
+    codes = {prn: gc.gencode(prn, 1)}
+    sats = [dict(prn=prn, doppler=2210.0, codephase=512.7, cn0=48.0, phase=0.3)]
+    nblocks, nmore = 8, 4                      # pushed before acquisition / while tracking
+    nsamples = nblocks * 65536
+    ntotal = (nblocks + nmore) * 65536
+    data = synth.make_if(codes, ntotal, f_if=4.092e6, dtype=1, sats=sats, seed=21)
+    f = tmp_path / "if.dat"
+    data.tofile(f)
+    ini = gc.sdrini()
+    ini.fend, ini.useif1, ini.useif2 = 10, 1, 0
+    ini.file1 = str(f).encode()
+    ini.dtype[0], ini.f_sf[0], ini.f_if[0], ini.f_cf[0] = 1, 16.368e6, 4.092e6, 1575.42e6
+    ini.trkcorrn, ini.trkcorrd, ini.trkcorrp = 6, 3, 6
+    for k, v in (("trkdllb", (5.0, 1.0)), ("trkpllb", (30.0, 10.0)), ("trkfllb", (200.0, 50.0))):
+        getattr(ini, k)[0], getattr(ini, k)[1] = v
+    ini.fp1 = None
+    assert L.rcvinit_file(C.byref(ini)) == 0
+    for _ in range(nblocks):
+        L.file_pushtomembuf()
+    st = gc.sdrstat()
+    assert st.buffcnt == nblocks and st.fendbuffsize == 65536
+
+    sdr = gc.SdrCh()
+    assert L.initsdrch(1, gc.SYS_GPS, prn, gc.CTYPE_L1CA, 1, 1, 1575.42e6, 16.368e6, 4.092e6, C.byref(sdr)) == 0
+    power = np.zeros(71 * 16368)
+    buffloc = L.sdracquisition(C.byref(sdr), power.ctypes.data)
+
+    # oracle on the same ring
+    ringlen = 5000 * 65536
+    big = np.ascontiguousarray(data)
+    o = orc.make_chan(prn, dtype=1, f_if=4.092e6, corrn=6, corrd=3, corrp=6)
+    xc = orc.codespectrum(o)
+    o.xcode = xc.ctypes.data
+    ring = orc.Ring()
+    ring.buff, ring.ringlen, ring.wrpos = big.ctypes.data, ringlen, nsamples
+    opower = np.zeros(71 * 16368)
+    it = C.c_int()
+    obuffloc = O.orc_sdracquisition(C.byref(o), C.byref(ring), opower.ctypes.data, 1, C.byref(it))
+    assert sdr.flagacq == o.flagacq == 1 and buffloc == obuffloc
+    assert (sdr.acq.acqcodei, sdr.acq.freqi, sdr.acq.acqfreq) == (o.acq.acqcodei, o.acq.freqi, o.acq.acqfreq)
+    assert abs(sdr.acq.acqfreq - 4.092e6 - 2210.0) <= 100.0
+    assert rel_err(power, opower) < 1e-4
+    assert sdr.trk.carrfreq == o.carrfreq and sdr.trk.codefreq == o.codefreq
+
+    # the grabber keeps delivering blocks while the channel tracks
+    for _ in range(nmore):
+        L.file_pushtomembuf()
+    ring.wrpos = ntotal
+    # tracking loop before bit sync: pll/dll every code period (ref src/sdrmain.c:272-276)
+    cnt, IP = 0, []
+    for _ in range(12):
+        L.sdrtracking(C.byref(sdr), buffloc, cnt)
+        O.orc_sdrtracking(C.byref(o), C.byref(ring), obuffloc, 1)
+        assert sdr.flagtrk == o.flagtrk == 1 and sdr.currnsamp == o.currnsamp
+        for t in range(13):
+            assert sdr.trk.II[t] == o.II[t] and sdr.trk.QQ[t] == o.QQ[t]
+        assert sdr.trk.remcode == o.remcode and sdr.trk.remcarr == o.remcarr
+        L.cumsumcorr(C.byref(sdr.trk), 1)
+        O.orc_cumsumcorr(C.byref(o), 1)
+        L.pll(C.byref(sdr), C.byref(sdr.trk.prm1), sdr.ctime)
+        L.dll(C.byref(sdr), C.byref(sdr.trk.prm1), sdr.ctime)
+        O.orc_pll(C.byref(o), 0, o.ctime)
+        O.orc_dll(C.byref(o), 0, o.ctime)
+        assert sdr.trk.carrfreq == o.carrfreq and sdr.trk.codefreq == o.codefreq
+        IP.append(sdr.trk.II[0] ** 2 + sdr.trk.QQ[0] ** 2)
+        L.clearcumsumcorr(C.byref(sdr.trk))
+        O.orc_clearcumsumcorr(C.byref(o))
+        buffloc += sdr.currnsamp
+        obuffloc += o.currnsamp
+        cnt += 1
+    # the prompt correlator sits on the signal: power far above the noise floor of an absent PRN
+    assert min(IP) > 100 * (8.0 ** 2) * 16368 / 32 ** 2
+    # not enough samples buffered yet -> flagtrk 0 and nothing touched
+    before = sdr.trk.remcode
+    L.sdrtracking(C.byref(sdr), ntotal, cnt)
+    assert sdr.flagtrk == 0 and sdr.trk.remcode == before
+    L.freesdrch(C.byref(sdr))
