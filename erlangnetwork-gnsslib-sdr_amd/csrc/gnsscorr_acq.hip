@@ -120,14 +120,17 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
     const uint64_t base = buffloc % c.ringlen;
     const int8_t *ring = c.ring;
     const uint64_t ringlen = c.ringlen;
-    const double ps = __dmul_rn(__dmul_rn(freqs[c.freq_off + bin], (double)GC_CDIV), c.ti);
+    uint64_t A0, PS;
+    int kflip, neg;
+    gc_carrier_fx(0.0, freqs[c.freq_off + bin], c.ti, &A0, &PS, &kflip, &neg);   // phase starts at 0 (:761)
+    const uint64_t bias = (neg & 2) ? GC_FX_BIAS : 0ULL;
     const float sc = (float)((1.0 / 32.0) / (double)c.nfft);     // CSCALE/m, ref src/sdrcmn.c:764
 
     auto sample = [&](int s) -> float2 {
         if (s >= n2) return make_float2(0.f, 0.f);
         uint64_t pos = base + (uint64_t)s;
         if (pos >= ringlen) pos -= ringlen;
-        const int idx = ((int)__dmul_rn((double)s, ps)) & (GC_CDIV - 1);   // phase starts at 0 (:761)
+        const int idx = (int)(((uint64_t)s * PS + bias) >> 59);
         const int cs_ = aCos32[idx], sn_ = aSin32[idx];
         int I, Q;
         if (dtype == 2) {

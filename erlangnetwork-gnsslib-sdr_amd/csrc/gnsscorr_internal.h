@@ -46,12 +46,40 @@ struct GcTrkPlan {
 struct GcTrkUnit {
     uint64_t a_al;      // 16-byte aligned ring byte offset of the period's first sample group
     double   cs, ci;    // replica start phase (chips, in [0,len)) and chip step per sample
-    double   phis, ps;  // carrier phase at sample 0 and step per sample, in LUT steps
+    uint64_t phi_fx;    // carrier phase at sample 0, 2^64 = one LUT revolution (32 steps)
+    uint64_t ps_fx;     // carrier step per sample, same scale (two's complement)
     int      head;      // bytes between a_al and the first sample
     int      n;         // currnsamp
     int      G;         // 16-byte groups covering the period
     int      nt;        // replica length n + 2*smax
+    int      kflip;     // first sample at which the phase has the sign of the step
+    int      neg;       // bit 0: phase negative before kflip, bit 1: from kflip on
 };
+
+// Fixed-point carrier NCO shared by the tracking and acquisition kernels (and
+// restated by the CPU checker): index = trunc_toward_zero(phase) & 31 in exact
+// arithmetic, 59 fractional bits per LUT step (ref src/sdrcmn.c:649-661).
+#define GC_FX_BIAS ((1ULL << 59) - 1)
+__host__ __device__ inline void gc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0,
+                                              uint64_t *PS, int *kflip, int *neg)
+{
+    const double phis = phi0 * GC_CDIV / GC_DPI;          // exact operations only below this line
+    const double ps = freq * GC_CDIV * ti;
+    const double am = fmod(phis, 32.0);
+    const uint64_t a = (uint64_t)ldexp(fabs(am), 59);
+    const long long p = llrint(ldexp(ps, 59));
+    const uint64_t pm = (uint64_t)(p < 0 ? -p : p);
+    int n0 = am < 0, n1 = p < 0;
+    *A0 = am < 0 ? (uint64_t)0 - a : a;
+    *PS = (uint64_t)p;
+    if (a == 0) n0 = n1;
+    if (pm == 0 || n0 == n1) { *kflip = 0x7fffffff; n1 = n0; }
+    else {
+        const uint64_t kf = a / pm + (a % pm != 0);
+        *kflip = kf > 0x7fffffffULL ? 0x7fffffff : (int)kf;
+    }
+    *neg = n0 | (n1 << 1);
+}
 
 // Row statistics of the accumulated power after one acquisition iteration.
 struct GcAcqRow {

@@ -88,13 +88,14 @@ __global__ void power_kernel(const float2 *__restrict__ a, double *__restrict__ 
 
 // ref src/sdrcmn.c:633-669 (samples), closed-form phase; optional float2 output
 // scaled as cpxcpx() does (ref src/sdrcmn.c:185-195)
-__global__ void mix_kernel(const int8_t *__restrict__ data, int dtype, int n, double ps, double phis,
-                           short *__restrict__ I, short *__restrict__ Q, float2 *__restrict__ cpx,
-                           float scale)
+__global__ void mix_kernel(const int8_t *__restrict__ data, int dtype, int n, uint64_t A0, uint64_t PS,
+                           int kflip, int neg, short *__restrict__ I, short *__restrict__ Q,
+                           float2 *__restrict__ cpx, float scale)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const int idx = ((int)__fma_rn((double)k, ps, phis)) & 31;
+    const bool ng = k < kflip ? (neg & 1) : (neg >> 1);
+    const int idx = (int)((A0 + (uint64_t)k * PS + (ng ? GC_FX_BIAS : 0ULL)) >> 59);
     const int c = oCos32[idx], s = oSin32[idx];
     int vi, vq;
     if (dtype == 2) {
@@ -325,8 +326,10 @@ double mixcarr(const char *data, int dtype, double ti, int n, double freq, doubl
     if (!d || !dI || !dQ) { SDRPRINTF("error: mixcarr memory allocation\n"); return 0.0; }
     hipStream_t st = g.ctx->stream;
     hipMemcpyAsync(d, data, (size_t)n * dtype, hipMemcpyHostToDevice, st);
-    const double phis = phi0 * GC_CDIV / GC_DPI, ps = freq * GC_CDIV * ti;
-    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, dtype, n, ps, phis, dI, dQ,
+    uint64_t A0, PS;
+    int kflip, neg;
+    gc_carrier_fx(phi0, freq, ti, &A0, &PS, &kflip, &neg);
+    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, dtype, n, A0, PS, kflip, neg, dI, dQ,
                        (float2 *)nullptr, 0.0f);
     hipMemcpyAsync(II, dI, sizeof(short) * n, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(QQ, dQ, sizeof(short) * n, hipMemcpyDeviceToHost, st);
@@ -378,8 +381,10 @@ void pcorrelator(const char *data, int dtype, double ti, int n, double *freq, in
     hipMemcpyAsync(dP, P, sizeof(double) * (size_t)n * nfreq, hipMemcpyHostToDevice, st);
     const float sc = (float)(CSCALE / m);
     for (int i = 0; i < nfreq; i++) {
-        const double ps = freq[i] * GC_CDIV * ti;
-        hipLaunchKernelGGL(mix_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d, dtype, m, ps, 0.0,
+        uint64_t A0, PS;
+        int kflip, neg;
+        gc_carrier_fx(0.0, freq[i], ti, &A0, &PS, &kflip, &neg);
+        hipLaunchKernelGGL(mix_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d, dtype, m, A0, PS, kflip, neg,
                            (short *)nullptr, (short *)nullptr, x, sc);
         if (conv_dev(g.ctx, x, t, cx, m, n, 1, dP + (size_t)i * n)) {
             SDRPRINTF("error: pcorrelator: %s\n", gnsscorr_last_error());

@@ -105,9 +105,7 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     u.nt = p.n + 2 * c.smax;
     u.ci = __dmul_rn(c.ti, p.codefreq);
     u.cs = gc_code_start(p.coff, c.smax, u.ci, c.clen);
-    // carrier NCO, ref src/sdrcmn.c:649-650
-    u.phis = __ddiv_rn(__dmul_rn(p.phi0, (double)GC_CDIV), GC_DPI);
-    u.ps = __dmul_rn(__dmul_rn(p.carrfreq, (double)GC_CDIV), c.ti);
+    gc_carrier_fx(p.phi0, p.carrfreq, c.ti, &u.phi_fx, &u.ps_fx, &u.kflip, &u.neg);
     unit[i] = u;
     if (nsamp_out) nsamp_out[i] = p.n;
 }
@@ -144,6 +142,11 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(gc_s2, a), __builtin_bit_cast(gc_s2, b), c, false);
 }
+// a . b over four int8 lanes with a literal zero accumulator (VOP3P form: no register to clear)
+__device__ __forceinline__ int dot4z(unsigned a, unsigned b)
+{
+    return __builtin_amdgcn_sdot4((int)a, (int)b, 0, false);
+}
 
 // Workgroup (seg, epoch, channel): correlates the 16-byte sample groups
 // [seg*256*NIT, (seg+1)*256*NIT) of one code period against every tap and
@@ -156,14 +159,22 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
 template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict__ chan,
                                                        const GcTrkUnit *__restrict__ unit,
-                                                       int *__restrict__ partial, int nepoch, int nseg,
+                                                       int *__restrict__ partial, int nch, int nepoch, int nseg,
                                                        int ntap_stride, int ntap_lo, int max_n, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPG = 16 / DTYPE;                 // samples per 16-byte group
     constexpr int SEGG = 256 * NIT;                 // groups per segment
     constexpr int SEGS = SEGG * SPG;                // samples per segment
-    const int seg = blockIdx.x, e = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x;
+    // Workgroup order (speed only, never correctness): blocks b and b+8 tend to share an XCD, so
+    // every 8th block walks one epoch's channels and segments back to back -- the epoch's IF
+    // window is then fetched from HBM once and served to the other channels by that XCD's L2.
+    const int tid = threadIdx.x;
+    const int per_epoch = nch * nseg;
+    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int e = (qq / per_epoch) * 8 + slot, rr = qq % per_epoch;
+    const int ch = rr / nseg, seg = rr % nseg;
+    if (e >= nepoch) return;
     const GcChan &c = chan[ch];
     const int ntap = c.ntap;
     // this instantiation serves channels with ntap in (ntap_lo, NTAP] and this dtype
@@ -181,20 +192,25 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     const int klo = (g0 * 16 - head) / DTYPE;       // first sample index of the segment (may be < 0)
 
     // LDS carve (all offsets multiples of 16)
-    uint2 *lut = reinterpret_cast<uint2 *>(smem);                    // 32 x 8 B
-    int *red = reinterpret_cast<int *>(smem + 256);                  // 4 x 2*NTAP ints
+    // carrier LUT, one copy per sample position inside a dword (2 for IQ, 4 for real samples), each
+    // entry = the two int8 operand words that turn v_dot4 on the packed samples into I and Q
+    constexpr int LUTPOS = DTYPE == 2 ? 2 : 4;
+    constexpr int LUT_BYTES = 32 * 8 * LUTPOS;
+    uint2 *lut = reinterpret_cast<uint2 *>(smem);
+    int *red = reinterpret_cast<int *>(smem + LUT_BYTES);            // 4 x 2*NTAP ints
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
-    unsigned *rcp = reinterpret_cast<unsigned *>(smem + 256 + RED_BYTES);
+    unsigned *rcp = reinterpret_cast<unsigned *>(smem + LUT_BYTES + RED_BYTES);
 
-    if (tid < 32) {
-        const int cs_ = kCos32[tid], sn_ = kSin32[tid];
+    if (tid < 32 * LUTPOS) {
+        const int idx = tid & 31, pos = tid >> 5;
+        const int cs_ = kCos32[idx], sn_ = kSin32[idx];
         uint2 v;
         if (DTYPE == 2) {   // bytes [c,-s] -> I ; [s,c] -> Q for one IQ sample
-            v.x = (unsigned)(cs_ & 0xFF) | ((unsigned)((-sn_) & 0xFF) << 8);
-            v.y = (unsigned)(sn_ & 0xFF) | ((unsigned)(cs_ & 0xFF) << 8);
+            v.x = ((unsigned)(cs_ & 0xFF) | ((unsigned)((-sn_) & 0xFF) << 8)) << (16 * pos);
+            v.y = ((unsigned)(sn_ & 0xFF) | ((unsigned)(cs_ & 0xFF) << 8)) << (16 * pos);
         } else {
-            v.x = (unsigned)(cs_ & 0xFF);
-            v.y = (unsigned)(sn_ & 0xFF);
+            v.x = (unsigned)(cs_ & 0xFF) << (8 * pos);
+            v.y = (unsigned)(sn_ & 0xFF) << (8 * pos);
         }
         lut[tid] = v;
     }
@@ -257,7 +273,11 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     }
     __syncthreads();
 
-    const double phis = u.phis, ps = u.ps;
+    // carrier NCO: the truncation bias of a negative phase is folded into the start value unless
+    // the phase changes sign inside this period (then it is chosen per sample)
+    const bool flip = u.kflip < n;
+    const unsigned long long ps = u.ps_fx;
+    const unsigned long long phi0 = u.phi_fx + ((!flip && (u.neg & 1)) ? GC_FX_BIAS : 0ULL);
     int accI[NTAP], accQ[NTAP], toff[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; t++) {
@@ -294,18 +314,20 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         }
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
         unsigned ip[SPG / 2], qp[SPG / 2];
+        unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
 #pragma unroll
         for (int i = 0; i < SPG; i += 2) {
             int I[2], Q[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
-                const int k = kb + i + s2;
-                const double phi = __fma_rn((double)k, ps, phis);
-                const uint2 l = lut[((int)phi) & (GC_CDIV - 1)];
-                const int sh = DTYPE == 2 ? ((i + s2) & 1) * 16 : ((i + s2) & 3) * 8;
-                const int wd = (int)w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
-                I[s2] = __builtin_amdgcn_sdot4(wd, (int)(l.x << sh), 0, false);
-                Q[s2] = __builtin_amdgcn_sdot4(wd, (int)(l.y << sh), 0, false);
+                unsigned long long ph = phi;
+                if (flip) ph += (((kb + i + s2 < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
+                const int pos = DTYPE == 2 ? ((i + s2) & 1) : ((i + s2) & 3);
+                const uint2 l = lut[32 * pos + (int)(ph >> 59)];
+                const unsigned wd = w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
+                I[s2] = dot4z(wd, l.x);
+                Q[s2] = dot4z(wd, l.y);
+                phi += ps;
             }
             ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
             qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
@@ -390,14 +412,16 @@ int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
     constexpr int SEGS = 256 * NIT * (16 / DTYPE);
     const size_t npos = (((size_t)SEGS + 2 * smax_max + 1 + 15) / 16) * 16;
-    const int lds = (int)(256 + RED_BYTES + npos * 4);
+    const int lds = (int)((DTYPE == 2 ? 512 : 1024) + RED_BYTES + npos * 4);
     static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
     if (lds > 64 * 1024)
         GC_HIP(hipFuncSetAttribute((const void *)trk_corr_kernel<DTYPE, NTAP, NIT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    dim3 grid(nseg, nepoch, nch), block(256);
-    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP, NIT>), grid, block, lds, st, chan, unit, partial, nepoch, nseg,
-                       ntap_stride, ntap_lo, max_n, ablate);
+    const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
+    if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
+    dim3 grid((unsigned)total), block(256);
+    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP, NIT>), grid, block, lds, st, chan, unit, partial, nch, nepoch,
+                       nseg, ntap_stride, ntap_lo, max_n, ablate);
     GC_HIP(hipGetLastError());
     return 0;
 }
@@ -470,7 +494,6 @@ int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max)
 {
     trk_pick_nit();
-    if (nepoch > 65535 || nch > 65535) return gc_fail(GNSSCORR_EINVAL, "trk_corr: at most 65535 epochs per batch");
     if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_corr: tap offset %d samples (<= 64 supported)", smax_max);
     if (dtype == 2)
         return launch_corr_taps<2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);

@@ -151,8 +151,43 @@ double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
     return phase_remainder(phi);
 }
 
-/* closed form implemented by the HIP kernels: phi_k = fma(k, ps, phi_0);
- * the remainder is reduced with one floor instead of the subtract loop. */
+/* Closed form implemented by the HIP kernels: a 64-bit fixed-point NCO.  One
+ * LUT revolution (32 steps) is 2^64, i.e. 59 fractional bits per LUT step:
+ *   A0 = trunc(fmod(phi0*32/2pi, 32) * 2^59),  PS = rint(ps * 2^59)
+ *   N_k = A0 + k*PS  (exact integer),  index = trunc_toward_zero(N_k / 2^59) & 31
+ * which is the reference's ((int)phi)&31 evaluated in exact arithmetic (the step
+ * is quantised to 2^-59 LUT steps, ~1e-14 steps over a code period).  Negative
+ * phases truncate toward zero like the C cast (ref src/sdrcmn.c:654,661).
+ * The phase remainder stays the fp64 closed form of the running sum. */
+void orc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0, uint64_t *PS, int *kflip,
+                    int *neg0, int *neg1)
+{
+    const double phis = phi0 * ORC_CDIV / ORC_DPI;
+    const double ps = freq * ORC_CDIV * ti;
+    const double am = fmod(phis, 32.0);                       /* exact, sign of phis */
+    const double mag = ldexp(fabs(am), 59);                   /* < 2^64 */
+    const uint64_t a = (uint64_t)mag;                         /* truncation */
+    const long long p = llrint(ldexp(ps, 59));                /* |ps| < 16 */
+    const uint64_t pm = (uint64_t)(p < 0 ? -p : p);
+    *A0 = am < 0 ? (uint64_t)0 - a : a;
+    *PS = (uint64_t)p;
+    *neg0 = am < 0;
+    *neg1 = p < 0;
+    if (a == 0) *neg0 = *neg1;                                /* phase starts at exactly 0 */
+    if (pm == 0 || *neg0 == *neg1) { *kflip = 0x7fffffff; *neg1 = *neg0; }
+    else {
+        const uint64_t kf = a / pm + (a % pm != 0);           /* first k with |k*PS| >= |A0| */
+        *kflip = kf > 0x7fffffffULL ? 0x7fffffff : (int)kf;
+    }
+}
+
+static inline int carrier_index(uint64_t A0, uint64_t PS, int kflip, int neg0, int neg1, int k)
+{
+    const uint64_t phi = A0 + (uint64_t)(long long)k * PS;    /* mod 2^64 = mod 32 LUT steps */
+    const int neg = k < kflip ? neg0 : neg1;
+    return (int)((phi + (neg ? ((1ULL << 59) - 1) : 0)) >> 59);
+}
+
 double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
                       double freq, double phi0, short *I, short *Q)
 {
@@ -160,12 +195,12 @@ double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
     double phis = phi0 * ORC_CDIV / ORC_DPI;
     double ps = freq * ORC_CDIV * ti;
     double prem;
-    int k;
+    uint64_t A0, PS;
+    int kflip, neg0, neg1, k;
     orc_carrier_lut(cost, sint);
-    for (k = 0; k < n; k++) {
-        double phi = fma((double)k, ps, phis);
-        mix_one(data, dtype, k, ((int)phi) & (ORC_CDIV - 1), cost, sint, I, Q);
-    }
+    orc_carrier_fx(phi0, freq, ti, &A0, &PS, &kflip, &neg0, &neg1);
+    for (k = 0; k < n; k++)
+        mix_one(data, dtype, k, carrier_index(A0, PS, kflip, neg0, neg1, k), cost, sint, I, Q);
     prem = fma((double)n, ps, phis) * ORC_DPI / ORC_CDIV;
     if (prem > ORC_DPI) prem = fma(-floor(prem / ORC_DPI), ORC_DPI, prem);
     return prem;

@@ -18,9 +18,10 @@
  * Two flavours of the two NCOs are provided:
  *   *_seq : literal restatement (phase/code offset advanced by repeated += in
  *           fp64, exactly as the reference loops do);
- *   *_cf  : the closed form the HIP kernels implement (phase_k =
- *           fma(k, step, phase_0)); identical mathematics, differs from _seq
- *           only through fp64 rounding of the running sum.
+ *   *_cf  : the closed form the HIP kernels implement (carrier: 64-bit
+ *           fixed-point NCO, exact arithmetic; code: chip = trunc(fma(j, ci,
+ *           c_0))); identical mathematics, differs from _seq only through the
+ *           fp64 rounding of _seq's running sums.
  * GPU results are compared bit-exactly with _cf and to 1e-4 relative
  * (north_star tolerance) with _seq.
  */
@@ -51,6 +52,9 @@ double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
                        double freq, double phi0, short *I, short *Q);
 double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
                       double freq, double phi0, short *I, short *Q);
+/* start value / step / sign bookkeeping of the closed form's fixed-point carrier NCO */
+void orc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0, uint64_t *PS, int *kflip,
+                    int *neg0, int *neg1);
 
 /* ref src/sdrcmn.c:608-621 (literal) and closed form */
 double orc_rescode_seq(const short *code, int len, double coff, int smax,
