@@ -53,6 +53,11 @@ extern "C" int gnsscorr_create(gnsscorr_ctx **out, int device, void *stream)
         if (e != hipSuccess) { delete ctx; return gc_fail_hip(e, "hipStreamCreate", __FILE__, __LINE__); }
         ctx->own_stream = true;
     }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    for (int i = 0; i < 2 && ctx->stream2; i++) {
+        hipEventCreateWithFlags(&ctx->ev_plan[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ctx->ev_used[i], hipEventDisableTiming);
+    }
     *out = ctx;
     return GNSSCORR_OK;
 }
@@ -62,12 +67,16 @@ static void free_channels(gnsscorr_ctx *ctx)
     hipFree(ctx->dchan);  ctx->dchan = nullptr;
     hipFree(ctx->dcodes); ctx->dcodes = nullptr;
     hipFree(ctx->dfreqs); ctx->dfreqs = nullptr;
-    hipFree(ctx->dstate); ctx->dstate = nullptr;
+    for (int i = 0; i < 2; i++) { hipFree(ctx->dstate2[i]); ctx->dstate2[i] = nullptr; }
+    ctx->state_cur = 0;
+    ctx->ahead_valid = false;
+    ctx->state_touched = true;
 }
 
 static void free_trk_buffers(gnsscorr_ctx *ctx)
 {
-    hipFree(ctx->dplan);  ctx->dplan = nullptr;
+    for (int i = 0; i < 2; i++) { hipFree(ctx->dplan2[i]); ctx->dplan2[i] = nullptr; }
+    ctx->ahead_valid = false;
     hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
     hipFree(ctx->dcorrQ); ctx->dcorrQ = nullptr;
     hipFree(ctx->dnsamp); ctx->dnsamp = nullptr;
@@ -83,6 +92,7 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     gc_acq_free(ctx);
     free_trk_buffers(ctx);
     free_channels(ctx);
@@ -90,6 +100,11 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
         if (r.owned && r.mem) hipFree(r.mem);
     for (auto &kv : ctx->timers)
         for (auto &p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_plan[i]) hipEventDestroy(ctx->ev_plan[i]);
+        if (ctx->ev_used[i]) hipEventDestroy(ctx->ev_used[i]);
+    }
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -285,8 +300,10 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
     GC_HIP(hipMalloc((void **)&ctx->dchan, sizeof(GcChan) * nch));
     GC_HIP(hipMalloc((void **)&ctx->dcodes, codes.size()));
     GC_HIP(hipMalloc((void **)&ctx->dfreqs, sizeof(double) * freqs.size()));
-    GC_HIP(hipMalloc((void **)&ctx->dstate, sizeof(GcTrkState) * nch));
-    GC_HIP(hipMemsetAsync(ctx->dstate, 0, sizeof(GcTrkState) * nch, ctx->stream));
+    for (int i = 0; i < 2; i++) {
+        GC_HIP(hipMalloc((void **)&ctx->dstate2[i], sizeof(GcTrkState) * nch));
+        GC_HIP(hipMemsetAsync(ctx->dstate2[i], 0, sizeof(GcTrkState) * nch, ctx->stream));
+    }
     GC_HIP(hipMemcpyAsync(ctx->dcodes, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(ctx->dfreqs, freqs.data(), sizeof(double) * freqs.size(), hipMemcpyHostToDevice,
                           ctx->stream));
@@ -310,7 +327,12 @@ extern "C" int gnsscorr_trk_set_state(gnsscorr_ctx *ctx, int ch0, int nch, const
         return gc_fail(GNSSCORR_EINVAL, "trk_set_state: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
     static_assert(sizeof(gnsscorr_trkstate_t) == sizeof(GcTrkState), "state layout");
     GC_HIP(hipSetDevice(ctx->device));
-    GC_HIP(hipMemcpyAsync(ctx->dstate + ch0, st, sizeof(GcTrkState) * nch, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ahead_valid = false;                                         // ... and is dropped
+    ctx->state_touched = true;
+    GC_HIP(hipMemcpyAsync(ctx->dstate2[ctx->state_cur] + ch0, st, sizeof(GcTrkState) * nch, hipMemcpyHostToDevice,
+                          ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     return GNSSCORR_OK;
 }
@@ -320,7 +342,10 @@ extern "C" int gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch, gnssc
     if (!ctx || !st || ch0 < 0 || nch <= 0 || ch0 + nch > ctx->nch)
         return gc_fail(GNSSCORR_EINVAL, "trk_get_state: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
     GC_HIP(hipSetDevice(ctx->device));
-    GC_HIP(hipMemcpyAsync(st, ctx->dstate + ch0, sizeof(GcTrkState) * nch, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    GC_HIP(hipMemcpyAsync(st, ctx->dstate2[ctx->state_cur] + ch0, sizeof(GcTrkState) * nch, hipMemcpyDeviceToHost,
+                          ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     return GNSSCORR_OK;
 }
@@ -329,9 +354,13 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
 {
     const size_t units = (size_t)ctx->nch * nepoch;
     if (units <= ctx->plan_cap) return GNSSCORR_OK;
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
     GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ahead_valid) {            // a look-ahead plan advanced the state one batch: roll it back
+        ctx->ahead_valid = false;
+    }
     free_trk_buffers(ctx);
-    GC_HIP(hipMalloc((void **)&ctx->dplan, sizeof(GcTrkPlan) * units));
+    for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
     GC_HIP(hipMalloc((void **)&ctx->dunit, sizeof(GcTrkUnit) * units));
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
@@ -355,16 +384,48 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipSetDevice(ctx->device));
     int rc = ensure_trk_buffers(ctx, nepoch);
     if (rc) return rc;
-    {
-        GcTimed t(ctx, "trk_plan");
-        rc = gc_launch_trk_plan(ctx->stream, ctx->dchan, ctx->dstate, ctx->dplan, ctx->nch, nepoch);
+    // ---- planner: use the look-ahead plan if it matches, else plan now ----
+    hipStream_t ps = ctx->stream2 ? ctx->stream2 : ctx->stream;
+    const int slot = ctx->plan_slot;
+    if (!(ctx->ahead_valid && ctx->ahead_nepoch == nepoch)) {
+        if (ctx->ahead_valid) {        // planned for another batch length: the committed state is untouched
+            GC_HIP(hipStreamSynchronize(ps));
+            ctx->ahead_valid = false;
+        }
+        if (ctx->stream2) {            // order after whatever the main stream did to the state / buffers
+            GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));
+            GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[slot], 0));
+        }
+        GcTimed t(ctx, "trk_plan", ps);
+        rc = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
+                                ctx->dplan2[slot], ctx->nch, nepoch);
         if (rc) return rc;
+        if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[slot], ps));
     }
+    ctx->ahead_valid = false;
+    ctx->state_cur ^= 1;               // the plan's output state is now the committed one
+    if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
+    GcTrkPlan *dplan = ctx->dplan2[slot];
     {
         GcTimed t(ctx, "trk_expand");
-        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, ctx->dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch);
+        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch);
         if (rc) return rc;
     }
+    if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));
+    ctx->plan_slot ^= 1;
+    // ---- look ahead: plan the next batch of the same length while this one is correlated ----
+    if (ctx->stream2 && !ctx->state_touched) {
+        const int ns = ctx->plan_slot;
+        GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[ns], 0));        // its previous contents were consumed
+        GcTimed t(ctx, "trk_plan", ps);
+        rc = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
+                                ctx->dplan2[ns], ctx->nch, nepoch);
+        if (rc) return rc;
+        GC_HIP(hipEventRecord(ctx->ev_plan[ns], ps));
+        ctx->ahead_valid = true;
+        ctx->ahead_nepoch = nepoch;
+    }
+    ctx->state_touched = false;
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
     for (int dtype = 1; dtype <= 2; dtype++) {

@@ -45,9 +45,20 @@ struct gnsscorr_ctx {
     double *dfreqs = nullptr;
     int ntap = 0, smax_max = 0, max_n = 0;
 
-    // tracking
-    GcTrkState *dstate = nullptr;
-    GcTrkPlan *dplan = nullptr;
+    // tracking.  The planner (a short sequential NCO chain per channel) runs one batch ahead on
+    // its own stream: plan entries and the chained state are double buffered, so batch k+1 is
+    // planned while batch k is correlated.  A look-ahead plan is dropped when the caller changes
+    // the state or the batch length.
+    GcTrkState *dstate2[2] = {nullptr, nullptr};   // ping-pong; cur = index of the committed state
+    int state_cur = 0;
+    GcTrkPlan *dplan2[2] = {nullptr, nullptr};
+    int plan_slot = 0;                             // slot the next trk_run consumes
+    bool ahead_valid = false;                      // dplan2[plan_slot] already planned (look-ahead)
+    int ahead_nepoch = 0;
+    bool state_touched = true;                     // set_state since the last run: do not look ahead
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_plan[2] = {nullptr, nullptr};    // plan of slot s finished
+    hipEvent_t ev_used[2] = {nullptr, nullptr};    // expand consumed slot s
     GcTrkUnit *dunit = nullptr;
     size_t plan_cap = 0;
     double *dcorrI = nullptr, *dcorrQ = nullptr, *dsumI = nullptr, *dsumQ = nullptr;
@@ -69,16 +80,17 @@ struct GcTimed {
     gnsscorr_ctx *ctx;
     hipEvent_t a = nullptr, b = nullptr;
     const char *name;
-    GcTimed(gnsscorr_ctx *c, const char *n) : ctx(c), name(n)
+    hipStream_t st;
+    GcTimed(gnsscorr_ctx *c, const char *n, hipStream_t s = nullptr) : ctx(c), name(n), st(s ? s : c->stream)
     {
         if (!ctx->timing) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        hipEventRecord(a, ctx->stream);
+        hipEventRecord(a, st);
     }
     ~GcTimed()
     {
         if (!a) return;
-        hipEventRecord(b, ctx->stream);
+        hipEventRecord(b, st);
         ctx->timers[name].pending.emplace_back(a, b);
     }
 };

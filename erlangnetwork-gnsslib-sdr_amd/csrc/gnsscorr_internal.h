@@ -100,7 +100,7 @@ int gc_fail_hip(hipError_t e, const char *what, const char *file, int line);
 int gc_fail(int code, const char *fmt, ...);
 
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
-int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state,
+int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch);
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
                          int *nsamp_out, int nch, int nepoch);

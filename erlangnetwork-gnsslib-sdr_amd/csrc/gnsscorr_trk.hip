@@ -55,13 +55,14 @@ __device__ __forceinline__ double gc_code_rem(double coff, int smax, double ci, 
     return __dsub_rn(cend, __dmul_rn((double)smax, ci));
 }
 
-__global__ void trk_plan_kernel(const GcChan *__restrict__ chan, GcTrkState *__restrict__ state,
-                                GcTrkPlan *__restrict__ plan, int nch, int nepoch)
+__global__ void trk_plan_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
+                                GcTrkState *__restrict__ state_out, GcTrkPlan *__restrict__ plan, int nch,
+                                int nepoch)
 {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= nch) return;
     const GcChan c = chan[ch];
-    GcTrkState s = state[ch];
+    GcTrkState s = state_in[ch];
     const double ci = __dmul_rn(c.ti, s.codefreq);
     const double spc = __ddiv_rn(s.codefreq, c.f_sf);      // chips per sample
     for (int e = 0; e < nepoch; e++) {
@@ -80,7 +81,7 @@ __global__ void trk_plan_kernel(const GcChan *__restrict__ chan, GcTrkState *__r
         s.remcode = gc_code_rem(s.remcode, c.smax, ci, c.clen, n);
         s.buffloc += (uint64_t)(int64_t)n;
     }
-    state[ch] = s;
+    state_out[ch] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -156,6 +157,10 @@ __device__ __forceinline__ int dot4z(unsigned a, unsigned b)
 // sample position, (chip(j), chip(j+1)) as two int16, so that the pair a tap
 // needs for samples (k, k+1) is a single aligned dword whatever the tap
 // offset: the taps then cost one v_dot2_i32_i16 per two samples and rail.
+// The image is stored transposed -- position p at row p%8, column p/8 -- because
+// lane l works on samples 8l..8l+7: for a given tap and sample pair the 64 lanes
+// then read 64 consecutive dwords of one row (no bank conflicts) instead of
+// dwords 8 apart (8-way conflict).
 template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict__ chan,
                                                        const GcTrkUnit *__restrict__ unit,
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     const int nt = u.nt;
     const int8_t *code = c.code;
     const int npos = SEGS + 2 * smax + 1;           // positions this segment can touch
+    constexpr int RS = SEGS / 8 + 64;               // row stride (dwords) of the transposed image
     auto chipT = [&](int j) -> int { return (int)(long long)__fma_rn((double)j, ci, cs); };
     auto chipS = [&](int T) -> int { while (T >= clen) T -= clen; return (int)code[T]; };
     for (int q = tid; q * 16 < npos && !(ablate & 1); q += 256) {
@@ -265,11 +271,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
                 prev = nx;
             }
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(rcp + q * 16);
-        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
-        dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) rcp[(i & 7) * RS + 2 * q + (i >> 3)] = w[i];   // position 16q+i
     }
     __syncthreads();
 
@@ -332,13 +335,13 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
             ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
             qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
         }
-        const unsigned *rb = rcp + gl * SPG;
+        const unsigned *rb = rcp + gl * (SPG / 8);
 #pragma unroll
         for (int t = 0; t < NTAP; t++) {
-            const unsigned *rt = rb + toff[t];
 #pragma unroll
             for (int j = 0; j < SPG / 2; j++) {
-                const unsigned cp = rt[2 * j];
+                const int pj = toff[t] + 2 * j;                     // position relative to the group
+                const unsigned cp = rb[(pj & 7) * RS + (pj >> 3)];
                 accI[t] = dot2(ip[j], cp, accI[t]);
                 accQ[t] = dot2(qp[j], cp, accQ[t]);
             }
@@ -411,8 +414,8 @@ int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *
 {
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
     constexpr int SEGS = 256 * NIT * (16 / DTYPE);
-    const size_t npos = (((size_t)SEGS + 2 * smax_max + 1 + 15) / 16) * 16;
-    const int lds = (int)((DTYPE == 2 ? 512 : 1024) + RED_BYTES + npos * 4);
+    constexpr int RS = SEGS / 8 + 64;
+    const int lds = (int)((DTYPE == 2 ? 512 : 1024) + RED_BYTES + 8 * RS * 4);
     static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
     if (lds > 64 * 1024)
         GC_HIP(hipFuncSetAttribute((const void *)trk_corr_kernel<DTYPE, NTAP, NIT>,
@@ -469,11 +472,11 @@ int gc_trk_nseg(int dtype, int max_n)
     return (groups + 256 * g_trk_nit - 1) / (256 * g_trk_nit);
 }
 
-int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, GcTrkState *state, GcTrkPlan *plan,
-                       int nch, int nepoch)
+int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
+                       GcTrkPlan *plan, int nch, int nepoch)
 {
-    hipLaunchKernelGGL(trk_plan_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, chan, state, plan, nch,
-                       nepoch);
+    hipLaunchKernelGGL(trk_plan_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, chan, state_in, state_out, plan,
+                       nch, nepoch);
     GC_HIP(hipGetLastError());
     return 0;
 }

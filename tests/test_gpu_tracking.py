@@ -138,3 +138,34 @@ def test_correlator_symbol(gc, orc):
                                                 code16, 0)
         assert rel_err(II, sII) <= 1e-4 and rel_err(QQ, sQQ) <= 1e-4
         assert abs(remc.value - src_c) <= 1e-6 and abs(remp.value - src_p) <= 1e-6
+
+
+def test_consecutive_batches_and_lookahead_planner(gc, orc, engine):
+    """Batches chained on the device (the planner runs one batch ahead on its own stream): results and
+    the chained state must equal one long oracle run; a state change or another batch length drops
+    the look-ahead plan."""
+    nsamples = 16 * 8192 * 2
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[4, 19, 27], nsamples=nsamples,
+                                       seed=77, buffloc0=40)
+    got_II, got_QQ = [], []
+    for nb in (3, 3, 3, 2):                 # 3,3,3 exercises the look-ahead; 2 forces a re-plan
+        engine.trk_run(nb)
+        II, QQ, _ = engine.trk_fetch()
+        got_II.append(II)
+        got_QQ.append(QQ)
+    II = np.concatenate(got_II, axis=1)
+    QQ = np.concatenate(got_QQ, axis=1)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 11, mode=1)
+    assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+    fin = engine.trk_get_state()
+    for a, b in zip(fin, ofin):
+        assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
+    # closed-loop style: new frequencies between batches (as pll()/dll() would set them)
+    for s, f in zip(states, fin):
+        s.update(remcode=f["remcode"], remcarr=f["remcarr"], buffloc=f["buffloc"],
+                 carrfreq=s["carrfreq"] + 3.5, codefreq=s["codefreq"] - 0.01)
+    engine.trk_set_state(states)
+    engine.trk_run(3)
+    II2, QQ2, _ = engine.trk_fetch()
+    oII2, oQQ2, _, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 3, mode=1)
+    assert np.array_equal(II2, oII2) and np.array_equal(QQ2, oQQ2)
