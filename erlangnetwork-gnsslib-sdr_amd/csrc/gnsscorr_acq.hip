@@ -9,7 +9,8 @@
 // the replica has only nsamp non-zero samples and the data window 2*nsamp, so
 // lags 0..nsamp-1 never wrap for any L >= 2*nsamp-1 and the correlation values
 // are the same numbers (hard part 3).  A length-32768 transform is
-// done as two LDS-resident 16384-point transforms (gnsscorr_fft.h):
+// done as two LDS-resident 16384-point transforms (gnsscorr_fft.h) plus one
+// radix-2 stage; spectra stay in the FFT's pass order (no reordering anywhere):
 //
 //   acq_fwd  (per Doppler bin, iteration; shared by all SVs of a grid):
 //            carrier wipe-off of the 2*nsamp window straight from the HBM
@@ -46,7 +47,6 @@ struct GcAcqWork {
     GcAcqRow *rows = nullptr;   // [ch][iter][bin]
     int *iters = nullptr;       // [ch] iteration limit for acq_corr
     gnsscorr_acqres_t *res = nullptr;   // [ch]
-    float2 *Es = nullptr;       // acq_corr scratch: [ch][bin][16384]
     double *P = nullptr;        // one channel's power array (on demand)
     size_t P_elems = 0;
     int ngrid = 0, maxfreq = 0, maxintg = 0;
@@ -77,30 +77,26 @@ __global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k)
     tw32k[t] = make_float2((float)c, (float)s);
 }
 
-// Forward 32768-point transform of a sequence given by a per-sample functor,
-// result written split by parity: out[p][q] = X[2q + p].
+// Forward 32768-point transform of a sequence given by a per-sample functor:
+// one decimation-in-frequency stage on the fly, a[j] = x[j] + x[j+16384] feeds the even
+// frequencies and b[j] = (x[j] - x[j+16384]) w^j (w = exp(-2 pi i/32768)) the odd ones, then
+// two 16384-point transforms.  out[0][p] / out[1][p] = X[2 f(p)] / X[2 f(p) + 1], p in pass order.
 template <class F>
 __device__ __forceinline__ void fwd32k_store(F sample, float2 *lds, const float2 *__restrict__ tw16k,
                                              const float2 *__restrict__ tw32k, float2 *__restrict__ out,
                                              int tid)
 {
-    float2 v[32], e[32];
-    // even samples: input index j <-> sample 2j
-    gcfft::fft16k<-1>([&](int j) { return sample(2 * j); }, v, lds, tw16k, tid);
-#pragma unroll
-    for (int s = 0; s < 32; s++) e[s] = v[s];
+    auto store_to = [&](float2 *dst) {
+        return [dst](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+            float4 *d = reinterpret_cast<float4 *>(dst + p);
+            d[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
+            d[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
+        };
+    };
+    gcfft::dif<-1>([&](int j) { return cadd(sample(j), sample(j + GC_LH)); }, store_to(out), lds, tw16k, tid);
     __syncthreads();
-    gcfft::fft16k<-1>([&](int j) { return sample(2 * j + 1); }, v, lds, tw16k, tid);
-    // X[f] = E[f] + w^f O[f], X[f + 16384] = E[f] - w^f O[f], w = exp(-2 pi i/32768)
-#pragma unroll
-    for (int s = 0; s < 32; s++) {
-        const int f = tid + 512 * s;
-        const float2 t = cmul(v[s], tw32k[f]);
-        const float2 lo = cadd(e[s], t), hi = csub(e[s], t);
-        float2 *o = out + (size_t)(f & 1) * GC_LH + (f >> 1);
-        o[0] = lo;
-        o[GC_LH / 2] = hi;          // (f + 16384) >> 1 = (f >> 1) + 8192, same parity
-    }
+    gcfft::dif<-1>([&](int j) { return cmul(csub(sample(j), sample(j + GC_LH)), tw32k[j]); },
+                   store_to(out + GC_LH), lds, tw16k, tid);
 }
 
 // acq_fwd: grid (bin, iteration, grid group)
@@ -216,14 +212,10 @@ __device__ __forceinline__ void wg_sum_max(double &s, double &m, double *sd, int
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
     const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32k,
     const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
-    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg,
-    float2 *__restrict__ Escratch)
+    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
-    // E[] of the current iteration waits here (L2-resident, 128 KiB per workgroup) while the
-    // second transform owns the registers
-    float2 *Es = Escratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GC_LH;
     double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 16 doubles
     int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 128);       // 8 ints
     const int bin = blockIdx.x, tid0 = threadIdx.x;
@@ -234,39 +226,56 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
     const float2 *Cc = C + (size_t)ch * GC_L;
     const float invL2 = 1.0f / ((float)GC_L * (float)GC_L);
 
+    // lane `tid` owns lags k = tid + 512*h + 1024*q (h < 2, q < 16): register index 16*h + q
     double P[32];
 #pragma unroll
     for (int s = 0; s < 32; s++) P[s] = 0.0;
 
     for (int it = 0; it < nit; it++) {
-        // Opaque copy of the lane id: keeps the ~200 address computations of one iteration from
-        // being hoisted out of the loop (they would be spilled to scratch, not kept in VGPRs).
+        // Opaque copy of the lane id: keeps the address computations of one iteration from being
+        // hoisted out of the loop (they would be spilled to scratch, not kept in VGPRs).
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const float2 *Xb = X + (((size_t)c.grid * maxintg + it) * maxfreq + bin) * GC_L;
-        float2 v[32];
-        // E = IFFT16k(Y[2q]), O = IFFT16k(Y[2q+1]) with Y = X conj(C) (ref src/sdrcmn.c:236-240;
-        // the reference's extra minus sign vanishes under |.|^2)
-        gcfft::fft16k<+1>([&](int q) { return cmulc(Xb[q], Cc[q]); }, v, lds, tw16k, tid);
+        float2 e[32];
+        // E = IFFT16k(Y[even f]), O = IFFT16k(Y[odd f]) with Y = X conj(C) (ref src/sdrcmn.c:236-240;
+        // the reference's extra minus sign vanishes under |.|^2); X, C and Y all in pass order
+        auto product = [&](const float2 *xp, const float2 *cp) {
+            return [xp, cp](int p, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+                const float4 xa = *reinterpret_cast<const float4 *>(xp + p), xb = *reinterpret_cast<const float4 *>(xp + p + 2);
+                const float4 ca = *reinterpret_cast<const float4 *>(cp + p), cb = *reinterpret_cast<const float4 *>(cp + p + 2);
+                x0 = cmulc(make_float2(xa.x, xa.y), make_float2(ca.x, ca.y));
+                x1 = cmulc(make_float2(xa.z, xa.w), make_float2(ca.z, ca.w));
+                x2 = cmulc(make_float2(xb.x, xb.y), make_float2(cb.x, cb.y));
+                x3 = cmulc(make_float2(xb.z, xb.w), make_float2(cb.z, cb.w));
+            };
+        };
+        gcfft::dit<+1>(product(Xb, Cc),
+                       [&](int h, int, float2 (&a)[16]) {
 #pragma unroll
-        for (int s = 0; s < 32; s++) Es[tid + 512 * s] = v[s];     // same lane reads it back below
+                           for (int q = 0; q < 16; q++) e[16 * h + q] = a[q];
+                       },
+                       lds, tw16k, tid);
         __syncthreads();
-        gcfft::fft16k<+1>([&](int q) { return cmulc(Xb[GC_LH + q], Cc[GC_LH + q]); }, v, lds, tw16k, tid);
         // y[k] = E[k] + conj(w^k) O[k]; P[k] += |y|^2 / L^2 (ref src/sdrcmn.c:244-246 with the
         // reference's m-point scaling folded: (m/L)^2/m^2 = 1/L^2)
+        gcfft::dit<+1>(product(Xb + GC_LH, Cc + GC_LH),
+                       [&](int h, int o, float2 (&a)[16]) {
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int k = tid + 512 * s;
-            const float2 y = cadd(Es[k], cmulc(v[s], tw32k[k]));
-            const float pw = fmaf(y.x, y.x, y.y * y.y) * invL2;
-            P[s] += (double)pw;
-        }
+                           for (int q = 0; q < 16; q++) {
+                               const int k = o + 1024 * q;
+                               const float2 y = cadd(e[16 * h + q], cmulc(a[q], tw32k[k]));
+                               const float pw = fmaf(y.x, y.x, y.y * y.y) * invL2;
+                               P[16 * h + q] += (double)pw;
+                           }
+                       },
+                       lds, tw16k, tid);
 
         // row statistics for checkacquisition()
         MaxIdx m; m.v = -1.0; m.k = 0x7fffffff;
 #pragma unroll
         for (int s = 0; s < 32; s++) {
-            const int k = tid + 512 * s;
+            const int k = tid + 512 * (s >> 4) + 1024 * (s & 15);
             if (k < n) { MaxIdx t; t.v = P[s]; t.k = k; m = better(m, t); }
         }
         m = wg_argmax(m, sd, si, tid);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
         double so = 0.0, mo = -1.0;
 #pragma unroll
         for (int s = 0; s < 32; s++) {
-            const int k = tid + 512 * s;
+            const int k = tid + 512 * (s >> 4) + 1024 * (s & 15);
             if (k < n) {
                 const bool outside = (exs <= exe) ? (k < exs || k > exe) : (k < exs && k > exe);
                 if (outside) so += P[s];
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
     if (Pout) {
 #pragma unroll
         for (int s = 0; s < 32; s++) {
-            const int k = tid0 + 512 * s;
+            const int k = tid0 + 512 * (s >> 4) + 1024 * (s & 15);
             if (k < n) Pout[(size_t)bin * n + k] = P[s];
         }
     }
@@ -341,7 +350,8 @@ __global__ void fill_int_kernel(int *p, const GcChan *__restrict__ chan, int nch
     if (i < nch) p[i] = chan[i].intg;
 }
 
-// stand-alone batch FFT (op-level entry point and tests): grid (batch)
+// stand-alone batch FFT (op-level entry point and tests): grid (batch); natural order in and out
+// (the pass-order result is scattered to its frequency on the way out)
 template <int S>
 __global__ __launch_bounds__(GC_FFT_THREADS) void fft16k_kernel(const float2 *__restrict__ in,
                                                                 float2 *__restrict__ out,
@@ -352,10 +362,12 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void fft16k_kernel(const float2 *__
     const int tid = threadIdx.x;
     const float2 *x = in + (size_t)blockIdx.x * GC_LH;
     float2 *y = out + (size_t)blockIdx.x * GC_LH;
-    float2 v[32];
-    gcfft::fft16k<S>([&](int j) { return x[j]; }, v, lds, tw16k, tid);
-#pragma unroll
-    for (int s = 0; s < 32; s++) y[tid + 512 * s] = v[s];
+    gcfft::dif<S>([&](int j) { return x[j]; },
+                  [&](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                      y[gcfft::freq_of(p)] = x0; y[gcfft::freq_of(p + 1)] = x1;
+                      y[gcfft::freq_of(p + 2)] = x2; y[gcfft::freq_of(p + 3)] = x3;
+                  },
+                  lds, tw16k, tid);
 }
 
 // power spectrum of a 16384- or 32768-point sequence (cpxpspec, ref src/sdrcmn.c:261-276)
@@ -367,31 +379,24 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void pspec_kernel(const float2 *__r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     const int tid = threadIdx.x;
-    float2 v[32];
+    auto power_to = [&](int mul, int add) {
+        return [=](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+            const float2 xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int f = mul * gcfft::freq_of(p + i) + add;
+                const double pw = (double)fmaf(xs[i].x, xs[i].x, xs[i].y * xs[i].y);
+                pspec[f] = flagsum ? pspec[f] + pw : pw;
+            }
+        };
+    };
     if (n == GC_LH) {
-        gcfft::fft16k<-1>([&](int j) { return in[j]; }, v, lds, tw16k, tid);
-#pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int f = tid + 512 * s;
-            const double p = (double)fmaf(v[s].x, v[s].x, v[s].y * v[s].y);
-            pspec[f] = flagsum ? pspec[f] + p : p;
-        }
+        gcfft::dif<-1>([&](int j) { return in[j]; }, power_to(1, 0), lds, tw16k, tid);
     } else {
-        float2 e[32];
-        gcfft::fft16k<-1>([&](int j) { return in[2 * j]; }, v, lds, tw16k, tid);
-#pragma unroll
-        for (int s = 0; s < 32; s++) e[s] = v[s];
+        gcfft::dif<-1>([&](int j) { return cadd(in[j], in[j + GC_LH]); }, power_to(2, 0), lds, tw16k, tid);
         __syncthreads();
-        gcfft::fft16k<-1>([&](int j) { return in[2 * j + 1]; }, v, lds, tw16k, tid);
-#pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int f = tid + 512 * s;
-            const float2 t = cmul(v[s], tw32k[f]);
-            const float2 lo = cadd(e[s], t), hi = csub(e[s], t);
-            const double pl = (double)fmaf(lo.x, lo.x, lo.y * lo.y), ph = (double)fmaf(hi.x, hi.x, hi.y * hi.y);
-            pspec[f] = flagsum ? pspec[f] + pl : pl;
-            pspec[f + GC_LH] = flagsum ? pspec[f + GC_LH] + ph : ph;
-        }
+        gcfft::dif<-1>([&](int j) { return cmul(csub(in[j], in[j + GC_LH]), tw32k[j]); }, power_to(2, 1), lds,
+                       tw16k, tid);
     }
 }
 
@@ -405,7 +410,7 @@ void gc_acq_free(gnsscorr_ctx *ctx)
     GcAcqWork *w = ctx->acq;
     if (!w) return;
     hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
-    hipFree(w->iters); hipFree(w->res); hipFree(w->P); hipFree(w->Es);
+    hipFree(w->iters); hipFree(w->res); hipFree(w->P);
     hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos);
     delete w;
     ctx->acq = nullptr;
@@ -453,7 +458,6 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&w->X, sizeof(float2) * w->X_elems));
     GC_HIP(hipMalloc((void **)&w->C, sizeof(float2) * (size_t)nch * GC_L));
     GC_HIP(hipMalloc((void **)&w->rows, sizeof(GcAcqRow) * (size_t)nch * w->maxintg * w->maxfreq));
-    GC_HIP(hipMalloc((void **)&w->Es, sizeof(float2) * (size_t)nch * w->maxfreq * GC_LH));
     GC_HIP(hipMalloc((void **)&w->iters, sizeof(int) * nch));
     GC_HIP(hipMalloc((void **)&w->res, sizeof(gnsscorr_acqres_t) * nch));
     GC_HIP(hipMalloc((void **)&w->d_grid_chan, sizeof(int) * w->ngrid));
@@ -506,7 +510,7 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
         GcTimed t(ctx, "acq_corr");
         hipLaunchKernelGGL(acq_corr_kernel, dim3(w->maxfreq, ctx->nch), dim3(GC_FFT_THREADS), lds, ctx->stream,
                            ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, (double *)nullptr, 0,
-                           w->maxfreq, w->maxintg, w->Es);
+                           w->maxfreq, w->maxintg);
     }
     GC_HIP(hipGetLastError());
     {
@@ -548,7 +552,7 @@ extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
     // with identical values
     hipLaunchKernelGGL(acq_corr_kernel, dim3(c.nfreq, 1), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
                        ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, w->P, ch, w->maxfreq,
-                       w->maxintg, w->Es);
+                       w->maxintg);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));

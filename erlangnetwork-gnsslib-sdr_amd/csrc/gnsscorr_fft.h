@@ -3,23 +3,33 @@
 // (it stands where the reference calls FFTW: cpxfft/cpxifft, ref
 // src/sdrcmn.c:134-175).
 //
-// 16384 = 4 * 16 * 16 * 16.  Stockham auto-sort, four passes over a single
-// 128 KiB LDS image; each thread owns 32 points, so a pass reads all of its
-// operands into registers, meets the workgroup barrier, and only then writes
-// the image back in the permuted order (in place, no second buffer).
-//   pass 0  radix-4 , no twiddles, operands come from the caller's registers
-//   pass 1  radix-16, sub-transform length 64
-//   pass 2  radix-16, sub-transform length 1024
-//   pass 3  radix-16, sub-transform length 16384, results stay in registers
-// Twiddles w^r (r = 1..15) are built from one table entry w = exp(-2*pi*i*t/16384)
-// by a product tree of depth <= 4, so each factor carries <= 4 float roundings.
+// 16384 = 16 * 16 * 16 * 4, in place in one (padded) 136 KiB LDS image.
+//   dif<S> : natural-order input  -> output in "pass order" (digit reversed)
+//            passes: radix-16 on sub-transform sizes 16384, 1024, 64, then radix-4
+//   dit<S> : pass-order input     -> natural-order output
+//            passes: radix-4, then radix-16 on sizes 64, 1024, 16384
+// A spectrum produced by dif is consumed by dit without any reordering, which
+// is all the correlation needs: X and conj(C) meet element by element in pass
+// order.  Every butterfly reads and writes its own 16 (or 4) image slots, so a
+// lane holds only one butterfly (32 VGPRs) at a time and the only barriers are
+// the ones between passes.  The first pass takes its operands from a functor
+// (global memory / on-the-fly samples), the last pass hands its results to a
+// functor, so neither touches LDS twice.
+//
+// Position p = 1024*q1 + 64*q2 + 4*q3 + q4 of the pass-order image holds
+// frequency f = q1 + 16*q2 + 256*q3 + 4096*q4.
+//
+// Image padding: 4 float2 after every 64 (index i -> i + 4*(i>>6)); with it the
+// stride-4 pass touches 64 different banks per 32 lanes instead of 8.
+// Twiddles w^r (r = 1..15) come from one table entry w = exp(-2*pi*i*t/16384)
+// through a product tree of depth <= 4.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #define GC_FFT_N        16384
 #define GC_FFT_THREADS  512
-#define GC_FFT_LDS      (GC_FFT_N * 8)
+#define GC_FFT_LDS      ((GC_FFT_N + 4 * (GC_FFT_N >> 6)) * 8)      // 139264 bytes
 
 namespace gcfft {
 
@@ -44,6 +54,13 @@ template <int S>
 __device__ __forceinline__ float2 tw(float2 t)     // table holds forward twiddles
 {
     return S > 0 ? make_float2(t.x, -t.y) : t;
+}
+__device__ __forceinline__ int padi(int i) { return i + ((i >> 6) << 2); }
+
+// frequency held by pass-order position p
+__device__ __forceinline__ int freq_of(int p)
+{
+    return (p >> 10) + (((p >> 6) & 15) << 4) + (((p >> 2) & 15) << 8) + ((p & 3) << 12);
 }
 
 // 4-point DFT in place: X[k] = sum_r a[r] exp(S*2*pi*i*r*k/4)
@@ -106,69 +123,120 @@ __device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1)
     a[15] = cmul(a[15], cmul(w8, w7));
 }
 
-// One radix-16 pass for the butterfly with index j (0..1023) whose operands
-// are in a[16]: twiddle (sub-transform position k = j mod NS, period 16*NS),
-// transform, and return the LDS index of output r as base + r*NS.
-template <int S, int NS>
-__device__ __forceinline__ int pass16(float2 (&a)[16], int j, const float2 *__restrict__ tw16k)
-{
-    const int k = j & (NS - 1);
-    if (NS > 1) {
-        const float2 w1 = tw<S>(tw16k[k * (GC_FFT_N / (16 * NS))]);
-        twiddle16(a, w1);
+// Geometry of radix-16 butterfly b (0..1023) of the pass working on
+// sub-transforms of size M: element r lives at image index base + r*STEP
+// (padding included), o is the position inside the sub-transform.
+template <int M>
+struct Geo {
+    static constexpr int STRIDE = M / 16;
+    static constexpr int STEP = STRIDE >= 64 ? STRIDE + 4 * (STRIDE >> 6) : STRIDE;
+    __device__ static __forceinline__ int o(int b) { return b & (STRIDE - 1); }
+    __device__ static __forceinline__ int base(int b) { return padi((b / STRIDE) * M + (b & (STRIDE - 1))); }
+    __device__ static __forceinline__ float2 w1(const float2 *__restrict__ tw16k, int b)
+    {
+        return tw16k[o(b) * (GC_FFT_N / M)];
     }
+};
+
+// ---- decimation in frequency: natural in, pass order out --------------------
+template <int S, int M>
+__device__ __forceinline__ void dif16_lds(float2 *lds, const float2 *__restrict__ tw16k, int b)
+{
+    float2 a[16];
+    const int base = Geo<M>::base(b);
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = lds[base + r * Geo<M>::STEP];
     dft16<S>(a);
-    return (j - k) * 16 + k;
+    twiddle16(a, tw<S>(Geo<M>::w1(tw16k, b)));
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[base + r * Geo<M>::STEP] = a[r];
 }
 
-// Full transform of x[j] = load(j), j < 16384.  On exit v[s] = X[tid + 512*s]
-// (s < 32).  `lds` is the 128 KiB image; the caller must not touch it between
-// entry and exit, and a workgroup barrier is required before the image is
-// reused after exit (the last pass only reads).
-template <int S, class Load>
-__device__ __forceinline__ void fft16k(Load load, float2 (&v)[32], float2 *lds,
-                                       const float2 *__restrict__ tw16k, int tid)
+// load(j) -> x[j], j < 16384 natural order;  store(p, v0..v3) <- pass-order positions p..p+3
+template <int S, class Load, class Store>
+__device__ __forceinline__ void dif(Load load, Store store, float2 *lds, const float2 *__restrict__ tw16k,
+                                    int tid)
 {
-    // pass 0: radix 4, NS = 1: operands x[j + 4096*r], results y[4*j + r]
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const int j = tid + GC_FFT_THREADS * b;
-        float2 x0 = load(j), x1 = load(j + 4096), x2 = load(j + 8192), x3 = load(j + 12288);
+    for (int h = 0; h < 2; h++) {           // size 16384: operands straight from the functor
+        const int b = tid + GC_FFT_THREADS * h;
+        float2 a[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = load(b + 1024 * r);
+        dft16<S>(a);
+        twiddle16(a, tw<S>(tw16k[b]));
+        const int base = Geo<16384>::base(b);
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[base + r * Geo<16384>::STEP] = a[r];
+    }
+    __syncthreads();
+    dif16_lds<S, 1024>(lds, tw16k, tid);
+    dif16_lds<S, 1024>(lds, tw16k, tid + GC_FFT_THREADS);
+    __syncthreads();
+    dif16_lds<S, 64>(lds, tw16k, tid);
+    dif16_lds<S, 64>(lds, tw16k, tid + GC_FFT_THREADS);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {           // radix 4 on 4 adjacent slots, results leave through the functor
+        const int p = 4 * (tid + GC_FFT_THREADS * i);
+        const float4 *src = reinterpret_cast<const float4 *>(lds + padi(p));
+        const float4 u = src[0], v = src[1];
+        float2 x0 = make_float2(u.x, u.y), x1 = make_float2(u.z, u.w);
+        float2 x2 = make_float2(v.x, v.y), x3 = make_float2(v.z, v.w);
         dft4<S>(x0, x1, x2, x3);
-        float4 *dst = reinterpret_cast<float4 *>(lds + 4 * j);
+        store(p, x0, x1, x2, x3);
+    }
+}
+
+// ---- decimation in time: pass order in, natural out --------------------------
+template <int S, int M>
+__device__ __forceinline__ void dit16_lds(float2 *lds, const float2 *__restrict__ tw16k, int b)
+{
+    float2 a[16];
+    const int base = Geo<M>::base(b);
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = lds[base + r * Geo<M>::STEP];
+    twiddle16(a, tw<S>(Geo<M>::w1(tw16k, b)));
+    dft16<S>(a);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[base + r * Geo<M>::STEP] = a[r];
+}
+
+// load4(p, x0..x3) -> pass-order inputs p..p+3;  sink(h, o, a) <- results y[o + 1024*q] = a[q], q < 16,
+// called for h = 0, 1 with o = tid + 512*h (h is a compile-time constant after unrolling, so the
+// caller can index register arrays with it)
+template <int S, class Load4, class Sink>
+__device__ __forceinline__ void dit(Load4 load4, Sink sink, float2 *lds, const float2 *__restrict__ tw16k,
+                                    int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int p = 4 * (tid + GC_FFT_THREADS * i);
+        float2 x0, x1, x2, x3;
+        load4(p, x0, x1, x2, x3);
+        dft4<S>(x0, x1, x2, x3);
+        float4 *dst = reinterpret_cast<float4 *>(lds + padi(p));
         dst[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
         dst[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
     }
     __syncthreads();
-
-    float2 a0[16], a1[16];
-    // pass 1: NS = 4
-#pragma unroll
-    for (int r = 0; r < 16; r++) { a0[r] = lds[tid + 1024 * r]; a1[r] = lds[tid + 512 + 1024 * r]; }
+    dit16_lds<S, 64>(lds, tw16k, tid);
+    dit16_lds<S, 64>(lds, tw16k, tid + GC_FFT_THREADS);
     __syncthreads();
-    {
-        const int o0 = pass16<S, 4>(a0, tid, tw16k), o1 = pass16<S, 4>(a1, tid + 512, tw16k);
+    dit16_lds<S, 1024>(lds, tw16k, tid);
+    dit16_lds<S, 1024>(lds, tw16k, tid + GC_FFT_THREADS);
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) { lds[o0 + 4 * r] = a0[r]; lds[o1 + 4 * r] = a1[r]; }
+    for (int h = 0; h < 2; h++) {
+        const int b = tid + GC_FFT_THREADS * h;
+        float2 a[16];
+        const int base = Geo<16384>::base(b);
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = lds[base + r * Geo<16384>::STEP];
+        twiddle16(a, tw<S>(tw16k[b]));
+        dft16<S>(a);
+        sink(h, b, a);
     }
-    __syncthreads();
-    // pass 2: NS = 64
-#pragma unroll
-    for (int r = 0; r < 16; r++) { a0[r] = lds[tid + 1024 * r]; a1[r] = lds[tid + 512 + 1024 * r]; }
-    __syncthreads();
-    {
-        const int o0 = pass16<S, 64>(a0, tid, tw16k), o1 = pass16<S, 64>(a1, tid + 512, tw16k);
-#pragma unroll
-        for (int r = 0; r < 16; r++) { lds[o0 + 64 * r] = a0[r]; lds[o1 + 64 * r] = a1[r]; }
-    }
-    __syncthreads();
-    // pass 3: NS = 1024, outputs X[j + 1024*r] stay in registers
-#pragma unroll
-    for (int r = 0; r < 16; r++) { a0[r] = lds[tid + 1024 * r]; a1[r] = lds[tid + 512 + 1024 * r]; }
-    pass16<S, 1024>(a0, tid, tw16k);
-    pass16<S, 1024>(a1, tid + 512, tw16k);
-#pragma unroll
-    for (int r = 0; r < 16; r++) { v[2 * r] = a0[r]; v[2 * r + 1] = a1[r]; }
 }
 
 }  // namespace gcfft
