@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnsscorr.so")
+LIB_PATH = os.environ.get("GNSSCORR_LIB", os.path.join(_HERE, "libgnsscorr.so"))   # override: A/B builds
 
 MAXTAPS = 33
 CTYPE_L1CA, CTYPE_G1, CTYPE_L1SBAS = 1, 20, 27

@@ -25,6 +25,7 @@
 //            workgroup.  P only leaves the chip when the caller asks for it.
 //   acq_final (per channel): the decision of checkacquisition() after each
 //            iteration, first success wins (ref src/sdracq.c:39-42).
+#include <cstdlib>
 #include <vector>
 
 #include "gnsscorr_ctx.h"
@@ -175,6 +176,7 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b)
     return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a;
 }
 
+template <int NT>
 __device__ __forceinline__ MaxIdx wg_argmax(MaxIdx m, double *sd, int *si, int tid)
 {
 #pragma unroll
@@ -189,10 +191,11 @@ __device__ __forceinline__ MaxIdx wg_argmax(MaxIdx m, double *sd, int *si, int t
     __syncthreads();
     MaxIdx r; r.v = sd[0]; r.k = si[0];
 #pragma unroll
-    for (int w = 1; w < GC_FFT_THREADS / 64; w++) { MaxIdx t; t.v = sd[w]; t.k = si[w]; r = better(r, t); }
+    for (int w = 1; w < NT / 64; w++) { MaxIdx t; t.v = sd[w]; t.k = si[w]; r = better(r, t); }
     return r;
 }
 
+template <int NT>
 __device__ __forceinline__ void wg_sum_max(double &s, double &m, double *sd, int tid)
 {
 #pragma unroll
@@ -201,35 +204,46 @@ __device__ __forceinline__ void wg_sum_max(double &s, double &m, double *sd, int
         m = fmax(m, __shfl_xor(m, o, 64));
     }
     __syncthreads();
-    if ((tid & 63) == 0) { sd[tid >> 6] = s; sd[8 + (tid >> 6)] = m; }
+    if ((tid & 63) == 0) { sd[tid >> 6] = s; sd[16 + (tid >> 6)] = m; }
     __syncthreads();
-    s = sd[0]; m = sd[8];
+    s = sd[0]; m = sd[16];
 #pragma unroll
-    for (int w = 1; w < GC_FFT_THREADS / 64; w++) { s += sd[w]; m = fmax(m, sd[8 + w]); }
+    for (int w = 1; w < NT / 64; w++) { s += sd[w]; m = fmax(m, sd[16 + w]); }
 }
 
-// acq_corr: grid (bin, channel)
-__global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
+struct RawXC { float4 xa, xb, ca, cb; };
+
+// acq_corr: one workgroup of NT lanes per (bin, channel)
+template <int NT>
+__global__ __launch_bounds__(NT) void acq_corr_kernel(
     const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32k,
     const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
-    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg)
+    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg, int nchg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
-    double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 16 doubles
-    int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 128);       // 8 ints
-    const int bin = blockIdx.x, tid0 = threadIdx.x;
-    const int ch = Pout ? pout_ch : blockIdx.y;
+    double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 32 doubles
+    int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 256);       // 16 ints
+    // Workgroup order (speed only): blocks b, b+8, b+16, ... tend to share an XCD, so each XCD walks
+    // one Doppler bin across all channels before the next bin: the bin's forward spectra are pulled
+    // into that XCD's L2 once per iteration and shared by every SV.
+    const int tid0 = threadIdx.x;
+    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int bin = (qq / nchg) * 8 + slot;
+    const int ch = Pout ? pout_ch : qq % nchg;
+    if (bin >= maxfreq) return;
     const GcChan &c = chan[ch];
     if (bin >= c.nfreq) return;
     const int n = c.nsamp, nit = iters[ch], nsc2 = 2 * c.nsampchip;
     const float2 *Cc = C + (size_t)ch * GC_L;
     const float invL2 = 1.0f / ((float)GC_L * (float)GC_L);
 
-    // lane `tid` owns lags k = tid + 512*h + 1024*q (h < 2, q < 16): register index 16*h + q
-    double P[32];
+    // lane `tid` owns lags k = tid + NT*h + 1024*q (h < 1024/NT, q < 16): register index 16*h + q
+    constexpr int NP = 16 * (1024 / NT);
+    constexpr int CHUNK = 4;                       // butterflies whose operands are in flight together
+    double P[NP];
 #pragma unroll
-    for (int s = 0; s < 32; s++) P[s] = 0.0;
+    for (int s = 0; s < NP; s++) P[s] = 0.0;
 
     for (int it = 0; it < nit; it++) {
         // Opaque copy of the lane id: keeps the address computations of one iteration from being
@@ -237,20 +251,26 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const float2 *Xb = X + (((size_t)c.grid * maxintg + it) * maxfreq + bin) * GC_L;
-        float2 e[32];
+        float2 e[NP];
         // E = IFFT16k(Y[even f]), O = IFFT16k(Y[odd f]) with Y = X conj(C) (ref src/sdrcmn.c:236-240;
         // the reference's extra minus sign vanishes under |.|^2); X, C and Y all in pass order
-        auto product = [&](const float2 *xp, const float2 *cp) {
-            return [xp, cp](int p, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
-                const float4 xa = *reinterpret_cast<const float4 *>(xp + p), xb = *reinterpret_cast<const float4 *>(xp + p + 2);
-                const float4 ca = *reinterpret_cast<const float4 *>(cp + p), cb = *reinterpret_cast<const float4 *>(cp + p + 2);
-                x0 = cmulc(make_float2(xa.x, xa.y), make_float2(ca.x, ca.y));
-                x1 = cmulc(make_float2(xa.z, xa.w), make_float2(ca.z, ca.w));
-                x2 = cmulc(make_float2(xb.x, xb.y), make_float2(cb.x, cb.y));
-                x3 = cmulc(make_float2(xb.z, xb.w), make_float2(cb.z, cb.w));
+        auto fetch = [&](const float2 *xp, const float2 *cp) {
+            return [xp, cp](int p) {
+                RawXC r;
+                r.xa = *reinterpret_cast<const float4 *>(xp + p);
+                r.xb = *reinterpret_cast<const float4 *>(xp + p + 2);
+                r.ca = *reinterpret_cast<const float4 *>(cp + p);
+                r.cb = *reinterpret_cast<const float4 *>(cp + p + 2);
+                return r;
             };
         };
-        gcfft::dit<+1>(product(Xb, Cc),
+        auto product = [](const RawXC &r, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+            x0 = cmulc(make_float2(r.xa.x, r.xa.y), make_float2(r.ca.x, r.ca.y));
+            x1 = cmulc(make_float2(r.xa.z, r.xa.w), make_float2(r.ca.z, r.ca.w));
+            x2 = cmulc(make_float2(r.xb.x, r.xb.y), make_float2(r.cb.x, r.cb.y));
+            x3 = cmulc(make_float2(r.xb.z, r.xb.w), make_float2(r.cb.z, r.cb.w));
+        };
+        gcfft::dit<+1, NT, CHUNK>(fetch(Xb, Cc), product,
                        [&](int h, int, float2 (&a)[16]) {
 #pragma unroll
                            for (int q = 0; q < 16; q++) e[16 * h + q] = a[q];
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
         __syncthreads();
         // y[k] = E[k] + conj(w^k) O[k]; P[k] += |y|^2 / L^2 (ref src/sdrcmn.c:244-246 with the
         // reference's m-point scaling folded: (m/L)^2/m^2 = 1/L^2)
-        gcfft::dit<+1>(product(Xb + GC_LH, Cc + GC_LH),
+        gcfft::dit<+1, NT, CHUNK>(fetch(Xb + GC_LH, Cc + GC_LH), product,
                        [&](int h, int o, float2 (&a)[16]) {
 #pragma unroll
                            for (int q = 0; q < 16; q++) {
@@ -274,24 +294,24 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
         // row statistics for checkacquisition()
         MaxIdx m; m.v = -1.0; m.k = 0x7fffffff;
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int k = tid + 512 * (s >> 4) + 1024 * (s & 15);
+        for (int s = 0; s < NP; s++) {
+            const int k = tid + NT * (s >> 4) + 1024 * (s & 15);
             if (k < n) { MaxIdx t; t.v = P[s]; t.k = k; m = better(m, t); }
         }
-        m = wg_argmax(m, sd, si, tid);
+        m = wg_argmax<NT>(m, sd, si, tid);
         int exs = m.k - nsc2; if (exs < 0) exs += n;
         int exe = m.k + nsc2; if (exe >= n) exe -= n;
         double so = 0.0, mo = -1.0;
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int k = tid + 512 * (s >> 4) + 1024 * (s & 15);
+        for (int s = 0; s < NP; s++) {
+            const int k = tid + NT * (s >> 4) + 1024 * (s & 15);
             if (k < n) {
                 const bool outside = (exs <= exe) ? (k < exs || k > exe) : (k < exs && k > exe);
                 if (outside) so += P[s];
                 if (outside || k == 0) mo = fmax(mo, P[s]);    // element 0 seeds maxvd()
             }
         }
-        wg_sum_max(so, mo, sd, tid);
+        wg_sum_max<NT>(so, mo, sd, tid);
         if (tid == 0) {
             GcAcqRow r;
             r.rowmax = m.v; r.sum_out = so; r.max_out = mo; r.argmax = m.k; r.pad = 0;
@@ -301,8 +321,8 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_corr_kernel(
     }
     if (Pout) {
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int k = tid0 + 512 * (s >> 4) + 1024 * (s & 15);
+        for (int s = 0; s < NP; s++) {
+            const int k = tid0 + NT * (s >> 4) + 1024 * (s & 15);
             if (k < n) Pout[(size_t)bin * n + k] = P[s];
         }
     }
@@ -429,7 +449,8 @@ static int acq_tables(gnsscorr_ctx *ctx)
         const int lds = GC_FFT_LDS + 256;
         GC_HIP(hipFuncSetAttribute((const void *)acq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)acq_code_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
         GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<+1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)pspec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -508,9 +529,15 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
                        ctx->dchan, ctx->nch);
     {
         GcTimed t(ctx, "acq_corr");
-        hipLaunchKernelGGL(acq_corr_kernel, dim3(w->maxfreq, ctx->nch), dim3(GC_FFT_THREADS), lds, ctx->stream,
-                           ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, (double *)nullptr, 0,
-                           w->maxfreq, w->maxintg);
+        static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
+        if (nt == 1024)
+            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(1024), lds + 256,
+                               ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows,
+                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
+        else
+            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(512), lds + 256,
+                               ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows,
+                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
     }
     GC_HIP(hipGetLastError());
     {
@@ -550,9 +577,9 @@ extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
     }
     // iteration count of the last run is still in w->iters[ch]; rows of this channel are rewritten
     // with identical values
-    hipLaunchKernelGGL(acq_corr_kernel, dim3(c.nfreq, 1), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
-                       ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, w->P, ch, w->maxfreq,
-                       w->maxintg);
+    hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
+                       ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, w->P, ch,
+                       w->maxfreq, w->maxintg, 1);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));

@@ -134,7 +134,11 @@ struct Geo {
     __device__ static __forceinline__ int base(int b) { return padi((b / STRIDE) * M + (b & (STRIDE - 1))); }
     __device__ static __forceinline__ float2 w1(const float2 *__restrict__ tw16k, int b)
     {
+#ifdef GC_ABLATE_TW
+        return make_float2(1.0f, 0.0f);
+#else
         return tw16k[o(b) * (GC_FFT_N / M)];
+#endif
     }
 };
 
@@ -153,13 +157,13 @@ __device__ __forceinline__ void dif16_lds(float2 *lds, const float2 *__restrict_
 }
 
 // load(j) -> x[j], j < 16384 natural order;  store(p, v0..v3) <- pass-order positions p..p+3
-template <int S, class Load, class Store>
+template <int S, int NT = GC_FFT_THREADS, class Load, class Store>
 __device__ __forceinline__ void dif(Load load, Store store, float2 *lds, const float2 *__restrict__ tw16k,
                                     int tid)
 {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {           // size 16384: operands straight from the functor
-        const int b = tid + GC_FFT_THREADS * h;
+    for (int h = 0; h < 1024 / NT; h++) {   // size 16384: operands straight from the functor
+        const int b = tid + NT * h;
         float2 a[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a[r] = load(b + 1024 * r);
@@ -170,15 +174,15 @@ __device__ __forceinline__ void dif(Load load, Store store, float2 *lds, const f
         for (int r = 0; r < 16; r++) lds[base + r * Geo<16384>::STEP] = a[r];
     }
     __syncthreads();
-    dif16_lds<S, 1024>(lds, tw16k, tid);
-    dif16_lds<S, 1024>(lds, tw16k, tid + GC_FFT_THREADS);
-    __syncthreads();
-    dif16_lds<S, 64>(lds, tw16k, tid);
-    dif16_lds<S, 64>(lds, tw16k, tid + GC_FFT_THREADS);
+#pragma unroll
+    for (int h = 0; h < 1024 / NT; h++) dif16_lds<S, 1024>(lds, tw16k, tid + NT * h);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {           // radix 4 on 4 adjacent slots, results leave through the functor
-        const int p = 4 * (tid + GC_FFT_THREADS * i);
+    for (int h = 0; h < 1024 / NT; h++) dif16_lds<S, 64>(lds, tw16k, tid + NT * h);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4096 / NT; i++) {   // radix 4 on 4 adjacent slots, results leave through the functor
+        const int p = 4 * (tid + NT * i);
         const float4 *src = reinterpret_cast<const float4 *>(lds + padi(p));
         const float4 u = src[0], v = src[1];
         float2 x0 = make_float2(u.x, u.y), x1 = make_float2(u.z, u.w);
@@ -202,33 +206,45 @@ __device__ __forceinline__ void dit16_lds(float2 *lds, const float2 *__restrict_
     for (int r = 0; r < 16; r++) lds[base + r * Geo<M>::STEP] = a[r];
 }
 
-// load4(p, x0..x3) -> pass-order inputs p..p+3;  sink(h, o, a) <- results y[o + 1024*q] = a[q], q < 16,
-// called for h = 0, 1 with o = tid + 512*h (h is a compile-time constant after unrolling, so the
-// caller can index register arrays with it)
-template <int S, class Load4, class Sink>
-__device__ __forceinline__ void dit(Load4 load4, Sink sink, float2 *lds, const float2 *__restrict__ tw16k,
-                                    int tid)
+// fetch(p) -> raw operands of pass-order inputs p..p+3 (memory loads only, any struct);
+// make(raw, x0..x3) turns them into the four inputs.  The loads of CH butterflies are issued
+// back to back before the first use, so a lane has 4*CH 16-byte loads in flight instead of
+// paying the memory latency once per butterfly.
+// sink(h, o, a) <- results y[o + 1024*q] = a[q], q < 16,
+// called for h = 0 .. 1024/NT-1 with o = tid + NT*h (h is a compile-time constant after unrolling,
+// so the caller can index register arrays with it).  NT = lanes in the workgroup (512 or 1024).
+template <int S, int NT = GC_FFT_THREADS, int CH = 4, class Fetch, class Make, class Sink>
+__device__ __forceinline__ void dit(Fetch fetch, Make make, Sink sink, float2 *lds,
+                                    const float2 *__restrict__ tw16k, int tid)
 {
+    constexpr int NB = 4096 / NT;
+    static_assert(NB % CH == 0, "chunk must divide the butterflies per lane");
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int p = 4 * (tid + GC_FFT_THREADS * i);
-        float2 x0, x1, x2, x3;
-        load4(p, x0, x1, x2, x3);
-        dft4<S>(x0, x1, x2, x3);
-        float4 *dst = reinterpret_cast<float4 *>(lds + padi(p));
-        dst[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
-        dst[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
+    for (int i0 = 0; i0 < NB; i0 += CH) {
+        decltype(fetch(0)) raw[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) raw[c] = fetch(4 * (tid + NT * (i0 + c)));
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int p = 4 * (tid + NT * (i0 + c));
+            float2 x0, x1, x2, x3;
+            make(raw[c], x0, x1, x2, x3);
+            dft4<S>(x0, x1, x2, x3);
+            float4 *dst = reinterpret_cast<float4 *>(lds + padi(p));
+            dst[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
+            dst[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
+        }
     }
     __syncthreads();
-    dit16_lds<S, 64>(lds, tw16k, tid);
-    dit16_lds<S, 64>(lds, tw16k, tid + GC_FFT_THREADS);
-    __syncthreads();
-    dit16_lds<S, 1024>(lds, tw16k, tid);
-    dit16_lds<S, 1024>(lds, tw16k, tid + GC_FFT_THREADS);
+#pragma unroll
+    for (int h = 0; h < 1024 / NT; h++) dit16_lds<S, 64>(lds, tw16k, tid + NT * h);
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int b = tid + GC_FFT_THREADS * h;
+    for (int h = 0; h < 1024 / NT; h++) dit16_lds<S, 1024>(lds, tw16k, tid + NT * h);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 1024 / NT; h++) {
+        const int b = tid + NT * h;
         float2 a[16];
         const int base = Geo<16384>::base(b);
 #pragma unroll

@@ -220,6 +220,19 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         lut[tid] = v;
     }
 
+    // IF samples of this lane's groups: issued now, consumed after the replica is built, so the
+    // HBM/L2 latency hides behind the fill phase
+    const int8_t *ring = c.ring;
+    const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
+    uint4 vdata[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int g = g0 + tid + 256 * it;
+        uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
+        if (addr >= ringbytes) addr -= ringbytes;
+        vdata[it] = *reinterpret_cast<const uint4 *>(ring + addr);
+    }
+
     // ---- resampled replica, ref src/sdrcmn.c:608-621 in closed form --------------------------
     // position j of the replica (j = smax + k + tap offset) lives at rcp[j - klo]; chip index
     // T(j) = trunc(fma(j, ci, cs)) is non-decreasing in j, so a 17-position task needs two
@@ -288,16 +301,12 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         accQ[t] = 0;
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0);
     }
-    const int8_t *ring = c.ring;
-    const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
 
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int gl = tid + 256 * it, g = g0 + gl;
         if (g >= G || (ablate & 2)) break;
-        uint64_t addr = u.a_al + (uint64_t)g * 16;
-        if (addr >= ringbytes) addr -= ringbytes;
-        uint4 v = *reinterpret_cast<const uint4 *>(ring + addr);
+        uint4 v = vdata[it];
         const int kb = (g * 16 - head) / DTYPE;     // exact: head is a multiple of DTYPE
         const bool edge = kb < 0 || kb + SPG > n;
         if (__ballot(edge) != 0ULL) {               // only the period's first / last wavefront
