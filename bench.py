@@ -157,13 +157,17 @@ def main():
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev               # one rank per GPU; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")    # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     E = args.epochs
     # HBM ring = two chunks of E code periods; while one is correlated the next one lands in the
@@ -177,7 +181,7 @@ def main():
         host, sats = None, None
 
     stream = torch.cuda.current_stream()
-    eng = gc.Engine(local_rank, stream=stream.cuda_stream)
+    eng = gc.Engine(dev_index, stream=stream.cuda_stream)
     ring_t = torch.zeros(ringlen * 2, dtype=torch.int8, device=dev)         # the HBM ring of this rank
     eng.ring_create(1, 2, ringlen, ring_t.data_ptr())
     if rank == 0:
@@ -254,7 +258,7 @@ def main():
     out = {
         "metric": METRIC, "value": value, "unit": "correlations/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int8 samples, int32 accumulators, fp64 NCO",
+        "scaling": "weak", "vs_baseline": None, "dtype": "int8 samples x int8 carrier LUT -> int32 accumulators (64-bit fixed-point carrier NCO, fp64 code NCO)",
         "data": "synthetic", "x_realtime": x_rt,
         "config": {"workload": "BASELINE configs[2]: 32-SV GPS L1CA tracking, 5-tap E/P/L correlators "
                                "(CORRN=2, CORRD=3), 1 ms coherent, 16.368 Msps int8 IQ, per GPU",
