@@ -115,7 +115,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
     // window of iteration `it`: ref src/sdracq.c:24-32
     const uint64_t buffloc = grid_wrpos[g] - (uint64_t)(c.intg + 1) * n + (uint64_t)it * n;
     const uint64_t base = buffloc % c.ringlen;
-    const int8_t *ring = c.ring;
+    const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringlen = c.ringlen;
     uint64_t A0, PS;
     int kflip, neg;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *
     const GcChan &c = chan[ch];
     const int n = c.nsamp, clen = c.clen;
     const double ci = __dmul_rn(c.ti, c.crate);      // sdr->ci, ref src/sdrinit.c:605
-    const int8_t *code = c.code;
+    const gc_gptr_i8 code = (gc_gptr_i8)c.code;
     // rescode(code, clen, 0, 0, ci, nsamp) zero-padded (ref src/sdrinit.c:650-651)
     auto sample = [&](int s) -> float2 {
         if (s >= n) return make_float2(0.f, 0.f);

@@ -10,6 +10,13 @@
 #define GC_CDIV     32
 #define GC_RCPAD    16                   // guard chips either side of the resampled code in LDS
 
+// Pointers read out of a struct are generic to the compiler, which then emits flat_load: those
+// count on the LDS counter too, so every LDS wait would also wait for HBM.  Ring and code-pool
+// pointers are always device global memory: say so.
+typedef const __attribute__((address_space(1))) int8_t *gc_gptr_i8;
+typedef unsigned gc_u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) gc_u4v *gc_gptr_u4;
+
 // Per-channel constants (HBM, one entry per channel).
 struct GcChan {
     const int8_t *ring;      // IF ring of the channel's front end

@@ -19,6 +19,7 @@
 //              integers (|sum| < 2^31), scaled by 1/32 at the end like the
 //              reference's CSCALE.
 #include <cstdlib>
+#include <type_traits>
 
 #include "gnsscorr_internal.h"
 
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
 
     // IF samples of this lane's groups: issued now, consumed after the replica is built, so the
     // HBM/L2 latency hides behind the fill phase
-    const int8_t *ring = c.ring;
+    const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
     uint4 vdata[NIT];
 #pragma unroll
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         const int g = g0 + tid + 256 * it;
         uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
         if (addr >= ringbytes) addr -= ringbytes;
-        vdata[it] = *reinterpret_cast<const uint4 *>(ring + addr);
+        const gc_u4v t4 = *(gc_gptr_u4)(ring + addr);
+        vdata[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
     }
 
     // ---- resampled replica, ref src/sdrcmn.c:608-621 in closed form --------------------------
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     // evaluations plus a 4-step bisection when it holds one chip edge.
     const double ci = u.ci, cs = u.cs;
     const int nt = u.nt;
-    const int8_t *code = c.code;
+    const gc_gptr_i8 code = (gc_gptr_i8)c.code;
     const int npos = SEGS + 2 * smax + 1;           // positions this segment can touch
     constexpr int RS = SEGS / 8 + 64;               // row stride (dwords) of the transposed image
     auto chipT = [&](int j) -> int { return (int)(long long)__fma_rn((double)j, ci, cs); };
@@ -302,60 +304,67 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0);
     }
 
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int gl = tid + 256 * it, g = g0 + gl;
-        if (g >= G || (ablate & 2)) break;
-        uint4 v = vdata[it];
-        const int kb = (g * 16 - head) / DTYPE;     // exact: head is a multiple of DTYPE
-        const bool edge = kb < 0 || kb + SPG > n;
-        if (__ballot(edge) != 0ULL) {               // only the period's first / last wavefront
-            if (edge) {                             // blank the samples outside [0, n)
-                unsigned m[4];
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    m[d] = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int k = kb + (d * 4 + b) / DTYPE;
-                        if (k >= 0 && k < n) m[d] |= 0xFFu << (8 * b);
+    // the sign-flip variant (a carrier phase that crosses zero inside the period) is a separate copy
+    // of the loop, chosen once per workgroup, so the common copy stays one basic block per group
+    auto run = [&](auto flip_tag) {
+        constexpr bool FLIP = decltype(flip_tag)::value;
+    #pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int gl = tid + 256 * it, g = g0 + gl;
+            if (g >= G || (ablate & 2)) break;
+            uint4 v = vdata[it];
+            const int kb = (g * 16 - head) / DTYPE;     // exact: head is a multiple of DTYPE
+            const bool edge = kb < 0 || kb + SPG > n;
+            if (__ballot(edge) != 0ULL) {               // only the period's first / last wavefront
+                if (edge) {                             // blank the samples outside [0, n)
+                    unsigned m[4];
+    #pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        m[d] = 0;
+    #pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int k = kb + (d * 4 + b) / DTYPE;
+                            if (k >= 0 && k < n) m[d] |= 0xFFu << (8 * b);
+                        }
                     }
+                    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
                 }
-                v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+            }
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            unsigned ip[SPG / 2], qp[SPG / 2];
+            unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
+    #pragma unroll
+            for (int i = 0; i < SPG; i += 2) {
+                int I[2], Q[2];
+    #pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    unsigned long long ph = phi;
+                    if (FLIP) ph += (((kb + i + s2 < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
+                    const int pos = DTYPE == 2 ? ((i + s2) & 1) : ((i + s2) & 3);
+                    const uint2 l = lut[32 * pos + (int)(ph >> 59)];
+                    const unsigned wd = w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
+                    I[s2] = dot4z(wd, l.x);
+                    Q[s2] = dot4z(wd, l.y);
+                    phi += ps;
+                }
+                ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
+                qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
+            }
+            const unsigned *rb = rcp + gl * (SPG / 8);
+    #pragma unroll
+            for (int t = 0; t < NTAP; t++) {
+    #pragma unroll
+                for (int j = 0; j < SPG / 2; j++) {
+                    const int pj = toff[t] + 2 * j;                     // position relative to the group
+                    const unsigned cp = rb[(pj & 7) * RS + (pj >> 3)];
+                    accI[t] = dot2(ip[j], cp, accI[t]);
+                    accQ[t] = dot2(qp[j], cp, accQ[t]);
+                }
             }
         }
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        unsigned ip[SPG / 2], qp[SPG / 2];
-        unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
-#pragma unroll
-        for (int i = 0; i < SPG; i += 2) {
-            int I[2], Q[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                unsigned long long ph = phi;
-                if (flip) ph += (((kb + i + s2 < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
-                const int pos = DTYPE == 2 ? ((i + s2) & 1) : ((i + s2) & 3);
-                const uint2 l = lut[32 * pos + (int)(ph >> 59)];
-                const unsigned wd = w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
-                I[s2] = dot4z(wd, l.x);
-                Q[s2] = dot4z(wd, l.y);
-                phi += ps;
-            }
-            ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
-            qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
-        }
-        const unsigned *rb = rcp + gl * (SPG / 8);
-#pragma unroll
-        for (int t = 0; t < NTAP; t++) {
-#pragma unroll
-            for (int j = 0; j < SPG / 2; j++) {
-                const int pj = toff[t] + 2 * j;                     // position relative to the group
-                const unsigned cp = rb[(pj & 7) * RS + (pj >> 3)];
-                accI[t] = dot2(ip[j], cp, accI[t]);
-                accQ[t] = dot2(qp[j], cp, accQ[t]);
-            }
-        }
-    }
+
+    };
+    if (flip) run(std::true_type{}); else run(std::false_type{});
 
     // wavefront then workgroup reduction
     const int lane = tid & 63, wv = tid >> 6;
