@@ -237,6 +237,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.timing(False)
+    if os.environ.get("GNSSCORR_TRACE_OUT"):          # debug library only (-DGC_TRK_TRACE, tools/trk_trace.sh)
+        import ctypes
+        tb = np.zeros(4096 * 12, dtype=np.uint64)
+        gc.lib().gnsscorr_debug_trk_trace(ctypes.c_void_p(tb.ctypes.data))
+        np.save(os.environ["GNSSCORR_TRACE_OUT"], tb.reshape(4096, 12))
     k_ms, k_n = eng.timing_read("trk_corr")
     p_ms, p_n = eng.timing_read("trk_plan")
     s_ms, s_n = eng.timing_read("trk_finish")

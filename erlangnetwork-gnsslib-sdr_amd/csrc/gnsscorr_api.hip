@@ -259,7 +259,7 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
     ctx->hfreq.resize(nch);
     ctx->hcorrp.resize(nch);
     ctx->hchan.assign(nch, GcChan());
-    std::vector<int8_t> codes((size_t)nch * 1024, 0);
+    std::vector<int8_t> codes((size_t)nch * GC_CODEBLOCK, 0);
     std::vector<double> freqs;
     ctx->ntap = 1 + 2 * ch[0].corrn;
     ctx->smax_max = 0;
@@ -273,8 +273,8 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
         d.code = ctx->hcode[i].data();
         d.freq = ctx->hfreq[i].data();
         d.corrp = ctx->hcorrp[i].data();
-        for (int k = 0; k < d.clen; k++) codes[(size_t)i * 1024 + k] = (int8_t)d.code[k];
         GcChan &g = ctx->hchan[i];
+        gc_build_codeblock(d.code, d.clen, codes.data() + (size_t)i * GC_CODEBLOCK, &g.nedge, &g.pm1);
         g.dtype = d.dtype; g.clen = d.clen; g.nsamp = d.nsamp; g.nsampchip = d.nsampchip;
         g.ntap = 1 + 2 * d.corrn;
         g.smax = d.corrp[d.corrn - 1];
@@ -311,7 +311,7 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
         const GcRing &r = ctx->ring[ctx->hdesc[i].ftype - 1];
         ctx->hchan[i].ring = r.mem;
         ctx->hchan[i].ringlen = r.ringlen;
-        ctx->hchan[i].code = ctx->dcodes + (size_t)i * 1024;
+        ctx->hchan[i].code = ctx->dcodes + (size_t)i * GC_CODEBLOCK;
     }
     return upload_channels(ctx);
 }

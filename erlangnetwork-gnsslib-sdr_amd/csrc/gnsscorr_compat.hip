@@ -18,7 +18,7 @@
 // per-call scratch on the default context (guarded by ctx->mtx)
 struct GcOnce {
     int8_t *data = nullptr;  size_t data_cap = 0;    // scratch "ring" for host-supplied samples
-    int8_t *code = nullptr;                          // 1024 chips
+    int8_t *code = nullptr;                          // one code block
     GcChan *chan = nullptr;
     GcTrkPlan *plan = nullptr;
     GcTrkUnit *unit = nullptr;
@@ -31,7 +31,7 @@ static int once_init(gnsscorr_ctx *ctx)
 {
     if (g_once.chan) return 0;
     GC_HIP(hipSetDevice(ctx->device));
-    GC_HIP(hipMalloc((void **)&g_once.code, 1024));
+    GC_HIP(hipMalloc((void **)&g_once.code, GC_CODEBLOCK));
     GC_HIP(hipMalloc((void **)&g_once.chan, sizeof(GcChan)));
     GC_HIP(hipMalloc((void **)&g_once.plan, sizeof(GcTrkPlan)));
     GC_HIP(hipMalloc((void **)&g_once.unit, sizeof(GcTrkUnit)));
@@ -80,9 +80,9 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
     GcTrkPlan p;
     memset(&p, 0, sizeof(p));
     p.buffloc = buffloc; p.coff = coff; p.phi0 = phi0; p.carrfreq = freq; p.codefreq = crate; p.n = n;
-    int8_t chips[1024] = {0};
-    for (int i = 0; i < coden; i++) chips[i] = (int8_t)codein[i];
-    GC_HIP(hipMemcpyAsync(g_once.code, chips, 1024, hipMemcpyHostToDevice, ctx->stream));
+    static int8_t block[GC_CODEBLOCK];     // guarded by ctx->mtx; every call ends with a stream sync
+    gc_build_codeblock(codein, coden, block, &c.nedge, &c.pm1);
+    GC_HIP(hipMemcpyAsync(g_once.code, block, GC_CODEBLOCK, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(g_once.chan, &c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(g_once.plan, &p, sizeof(p), hipMemcpyHostToDevice, ctx->stream));
     const int nseg = gc_trk_nseg(dtype, n);

@@ -21,7 +21,7 @@ typedef const __attribute__((address_space(1))) gc_u4v *gc_gptr_u4;
 struct GcChan {
     const int8_t *ring;      // IF ring of the channel's front end
     uint64_t ringlen;        // samples
-    const int8_t *code;      // clen chips (+-1) in the code pool
+    const int8_t *code;      // code block in the code pool: chips, edge ranks, edge list (gc_build_codeblock)
     int    dtype, clen, nsamp, nsampchip;
     int    ntap, smax;
     int    tapoff[GNSSCORR_MAXTAPS];   // tap offsets in samples: 0,-s0,+s0,-s1,+s1,...
@@ -29,8 +29,37 @@ struct GcChan {
     // acquisition
     int    nfreq, intg, nfft, grid;    // grid = index of the (ring, freq grid) group
     int    freq_off;                   // offset into the frequency pool
-    int    pad0;
+    int    nedge;                      // chip edges per code period (entries of the edge list)
+    int    pm1, pad1;                  // pm1: every edge steps by +-2 (a +-1 code)
 };
+
+// Code block = GC_CODEBLOCK bytes per channel:
+//   [0, 1024)     int8 chips (clen of them, zero padded)
+//   [1024, 3072)  uint16 rank[x], x < clen: number of chip edges at chip indices <= x
+//   [3072, 7168)  int16 pairs (m, d): edge list sorted by m; d = code[m-1] - code[m] != 0, m-1 cyclic
+// A "chip edge" is a chip index at which the periodic code changes value; the prefix-sum
+// correlator (gnsscorr_trk.hip) visits only these.
+#define GC_CODEBLOCK 7168
+static inline void gc_build_codeblock(const short *code, int clen, int8_t *block, int *nedge, int *pm1)
+{
+    uint16_t *rank = (uint16_t *)(block + 1024);
+    int16_t *edge = (int16_t *)(block + 3072);
+    for (int i = 0; i < GC_CODEBLOCK; i++) block[i] = 0;
+    int ne = 0, all2 = 1;
+    for (int m = 0; m < clen; m++) {
+        block[m] = (int8_t)code[m];
+        const int d = (int)(int8_t)code[(m + clen - 1) % clen] - (int)(int8_t)code[m];
+        if (d != 0) {
+            edge[2 * ne] = (int16_t)m;
+            edge[2 * ne + 1] = (int16_t)d;
+            ne++;
+            if (d != 2 && d != -2) all2 = 0;
+        }
+        rank[m] = (uint16_t)ne;
+    }
+    *nedge = ne;
+    *pm1 = all2;
+}
 
 // Tracking state carried from epoch to epoch (ref sdrtrk_t, src/sdr.h:371-381).
 struct GcTrkState {
@@ -61,6 +90,7 @@ struct GcTrkUnit {
     int      nt;        // replica length n + 2*smax
     int      kflip;     // first sample at which the phase has the sign of the step
     int      neg;       // bit 0: phase negative before kflip, bit 1: from kflip on
+    double   inv_ci;    // 1/ci: first estimate of a chip's start sample (corrected against T itself)
 };
 
 // Fixed-point carrier NCO shared by the tracking and acquisition kernels (and

@@ -108,6 +108,7 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     u.ci = __dmul_rn(c.ti, p.codefreq);
     u.cs = gc_code_start(p.coff, c.smax, u.ci, c.clen);
     gc_carrier_fx(p.phi0, p.carrfreq, c.ti, &u.phi_fx, &u.ps_fx, &u.kflip, &u.neg);
+    u.inv_ci = 1.0 / u.ci;
     unit[i] = u;
     if (nsamp_out) nsamp_out[i] = p.n;
 }
@@ -139,6 +140,19 @@ __constant__ signed char kSin32[32] = {0, 6, 12, 18, 23, 27, 30, 31, 32, 31, 30,
                                        0, -6, -12, -18, -23, -27, -30, -31, -32, -31, -30, -27, -23, -18, -12, -6};
 
 typedef short gc_s2 __attribute__((ext_vector_type(2)));
+
+// Phase time stamps of sampled workgroups (debug builds only: -DGC_TRK_TRACE; tools/trk_trace.py)
+#ifdef GC_TRK_TRACE
+#define GC_TRACE_N 4096
+__device__ unsigned long long gc_trk_trace[GC_TRACE_N * 12];
+#define GC_STAMP(i) do { if (tr) tr[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gnsscorr_debug_trk_trace(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_trk_trace), sizeof(unsigned long long) * GC_TRACE_N * 12) == hipSuccess ? 0 : -1;
+}
+#else
+#define GC_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
 {
@@ -181,6 +195,20 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     const int e = (qq / per_epoch) * 8 + slot, rr = qq % per_epoch;
     const int ch = rr / nseg, seg = rr % nseg;
     if (e >= nepoch) return;
+#ifdef GC_TRK_TRACE
+    unsigned long long *tr = nullptr;
+    if (tid == 0 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < GC_TRACE_N) {
+        tr = gc_trk_trace + (blockIdx.x / 31) * 12;
+        tr[8] = wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tr[10] = ((unsigned long long)xcc << 32) | hw;
+        tr[11] = blockIdx.x;
+    }
+#endif
+    GC_STAMP(0);
     const GcChan &c = chan[ch];
     const int ntap = c.ntap;
     // this instantiation serves channels with ntap in (ntap_lo, NTAP] and this dtype
@@ -196,6 +224,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         return;
     }
     const int klo = (g0 * 16 - head) / DTYPE;       // first sample index of the segment (may be < 0)
+    GC_STAMP(1);
 
     // LDS carve (all offsets multiples of 16)
     // carrier LUT, one copy per sample position inside a dword (2 for IQ, 4 for real samples), each
@@ -235,6 +264,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         vdata[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
     }
 
+    GC_STAMP(2);
     // ---- resampled replica, ref src/sdrcmn.c:608-621 in closed form --------------------------
     // position j of the replica (j = smax + k + tap offset) lives at rcp[j - klo]; chip index
     // T(j) = trunc(fma(j, ci, cs)) is non-decreasing in j, so a 17-position task needs two
@@ -289,7 +319,9 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
 #pragma unroll
         for (int i = 0; i < 16; i++) rcp[(i & 7) * RS + 2 * q + (i >> 3)] = w[i];   // position 16q+i
     }
+    GC_STAMP(3);
     __syncthreads();
+    GC_STAMP(4);
 
     // carrier NCO: the truncation bias of a negative phase is folded into the start value unless
     // the phase changes sign inside this period (then it is chosen per sample)
@@ -365,6 +397,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
 
     };
     if (flip) run(std::true_type{}); else run(std::false_type{});
+    GC_STAMP(5);
 
     // wavefront then workgroup reduction
     const int lane = tid & 63, wv = tid >> 6;
@@ -377,6 +410,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         }
     }
     __syncthreads();
+    GC_STAMP(6);
     if (tid < ntap) {
         int si = 0, sq = 0;
 #pragma unroll
@@ -387,6 +421,336 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         pout[tid] = si;
         pout[ntap_stride + tid] = sq;
     }
+#ifdef GC_TRK_TRACE
+    if (tr) { tr[7] = __builtin_readcyclecounter(); tr[9] = wall_clock64(); }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// correlator, prefix-sum form
+// ---------------------------------------------------------------------------
+// The resampled code is piecewise constant (one chip lasts 1/ci samples), so a
+// tap's sum over a stretch of S samples is
+//     sum_k x[k] c[T(k + off)] = c_b P(S) + sum_{m=a+1..b} (c_{m-1} - c_m) P(B_m - off),
+// where x is the carrier-mixed sample, P(e) the sum of the stretch's first e
+// mixed samples, B_m = min{j : T(j) >= m} the replica position at which chip m
+// starts, and a..b the chips the stretch touches.  All terms are integers and
+// the identity is exact (Abel summation; sums wrap mod 2^32 and the true result
+// fits), so the result is bit-identical to the sample-by-sample correlator --
+// but the taps cost one prefix look-up per chip EDGE (a chip at which the code
+// changes value) instead of one multiply-add per sample: the per-sample work
+// left is the carrier mixing, whose chained v_dot4 accumulators ARE the
+// running sums.
+//
+// One workgroup serves one (channel, epoch) [or a long period's share of it]
+// in rounds of 256*NIT sample groups that reuse one LDS image:
+//   phase A  lane L mixes its NIT consecutive groups (two chained dot4 per
+//            sample) and stores the running sums loc[p][L] (p samples into
+//            the lane's span; row 0 is constant zero); a DPP scan over the
+//            wavefront and the per-wave totals turn the lane totals into
+//            lbase[L], the sum in front of the lane's span.
+//   phase B  one chip edge per thread: B_m from the closed-form code NCO (a
+//            reciprocal estimate, corrected against T itself), then per tap
+//            P = loc + lbase at the clamped sample position.
+// Accumulators stay in registers over the rounds; one reduction at the end.
+template <int DTYPE, int NIT>
+struct PsLayout {
+    static constexpr int SPG = 16 / DTYPE;                      // samples per 16-byte group
+    static constexpr int LSP = NIT * SPG;                       // samples per lane and round
+    static constexpr int RGRP = 256 * NIT;                      // groups per round
+    static constexpr int RSAMP = 256 * LSP;                     // samples per round
+    static constexpr int RS = 256 + 1;                          // + closing column (P = total there)
+    static constexpr int MAXR = 16;                             // rounds per workgroup, at most
+    static constexpr int LUTPOS = DTYPE == 2 ? 2 : 4;
+    static constexpr int LUT_BYTES = 32 * 8 * LUTPOS;
+    static constexpr int WT_OFF = LUT_BYTES;                    // wtot[4] int2
+    static constexpr int RI_OFF = WT_OFF + 32;                  // rinfo[MAXR] int4
+    static constexpr int LB_OFF = RI_OFF + MAXR * 16;
+    static constexpr int LOC_OFF = LB_OFF + ((RS * 8 + 15) & ~15);
+    static constexpr int RED_OFF = LOC_OFF + ((LSP * RS * 8 + 15) & ~15);
+    static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
+};
+
+__device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over the 64 lanes
+{
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    v = dpp_add<0x143, 0xC>(v);
+    return v;
+}
+
+template <int DTYPE, int NTAP, int NIT>
+__global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
+                                                          const GcTrkUnit *__restrict__ unit,
+                                                          int *__restrict__ partial, int nch, int nepoch, int nseg,
+                                                          int ntap_stride, int ntap_lo, int max_n, int rpw,
+                                                          int ablate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using L = PsLayout<DTYPE, NIT>;
+    constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, RS = L::RS;
+    const int tid = threadIdx.x;
+    const int per_epoch = nch * nseg;
+    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int e = (qq / per_epoch) * 8 + slot, rr = qq % per_epoch;
+    const int ch = rr / nseg, seg = rr % nseg;
+    if (e >= nepoch) return;
+#ifdef GC_TRK_TRACE
+    unsigned long long *tr = nullptr;
+    if (tid == 0 && (blockIdx.x % 7) == 0 && blockIdx.x / 7 < GC_TRACE_N) {
+        tr = gc_trk_trace + (blockIdx.x / 7) * 12;
+        tr[8] = wall_clock64();
+        tr[11] = blockIdx.x;
+    }
+#endif
+    GC_STAMP(0);
+    const GcChan &c = chan[ch];
+    const int ntap = c.ntap;
+    if (c.dtype != DTYPE || ntap > NTAP || ntap <= ntap_lo) return;
+
+    const GcTrkUnit u = unit[(size_t)ch * nepoch + e];
+    const int n = u.n, smax = c.smax, clen = c.clen, head = u.head, G = u.G;
+    int *pout = partial + (((size_t)ch * nepoch + e) * nseg + seg) * 2 * ntap_stride;
+    const int g0 = seg * RGRP * rpw;
+    const double ci = u.ci, cs = u.cs, inv = u.inv_ci;
+    // outside the reference's (nsamp+100) scratch, nothing left for this workgroup, or a code NCO
+    // this form does not serve (more than 4 chips per sample)
+    if (n <= 0 || n > max_n || g0 >= G || !(ci > 0.0 && ci <= 4.0)) {
+        if (tid < 2 * ntap_stride) pout[tid] = 0;
+        return;
+    }
+    const int klo = (g0 * 16 - head) / DTYPE;       // first sample index of the workgroup (may be < 0)
+    int nround = (G - g0 + RGRP - 1) / RGRP;
+    if (nround > rpw) nround = rpw;
+    GC_STAMP(1);
+
+    constexpr int LUTPOS = L::LUTPOS;
+    uint2 *lut = reinterpret_cast<uint2 *>(smem);
+    int2 *wtot = reinterpret_cast<int2 *>(smem + L::WT_OFF);          // [4] per-wave totals
+    int4 *rinfo = reinterpret_cast<int4 *>(smem + L::RI_OFF);         // [MAXR] {q0, q1, last chip, -}
+    int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF);         // [256 + 1]
+    int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [LSP][RS]
+    int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x 2*NTAP
+
+    const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
+    const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
+    const int wv = tid >> 6, lane = tid & 63;
+    auto load_round = [&](int r, uint4 *dst) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int g = g0 + r * RGRP + tid * NIT + it;
+            uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
+            if (addr >= ringbytes) addr -= ringbytes;
+            const gc_u4v t4 = *(gc_gptr_u4)(ring + addr);
+            dst[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+        }
+    };
+    uint4 vdata[NIT], vnext[NIT];
+    load_round(0, vdata);
+    GC_STAMP(2);
+
+    // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
+    // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
+    // T(j) = trunc(fma(j, ci, cs)).  Only chips at which the code changes value matter; they are
+    // numbered q = period * nedge + list index, and rank[] converts a chip number into that
+    // numbering.  Lane r prepares round r: the edges [q0, q1) its samples can touch and its last chip.
+    const gc_gptr_i8 code = (gc_gptr_i8)c.code;
+    const unsigned short __attribute__((address_space(1))) *rank =
+        (const unsigned short __attribute__((address_space(1))) *)(code + 1024);
+    const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)(code + 3072);
+    const int nedge = c.nedge;
+    auto chipT = [&](int j) -> int { return (int)__fma_rn((double)j, ci, cs); };
+    if (tid < nround) {
+        const int kl = klo + tid * RSAMP;
+        const int kfirst = kl > 0 ? kl : 0;
+        const int kend = (kl + RSAMP < n ? kl + RSAMP : n);       // one past the round's last real sample
+        int ma = chipT(kfirst), mb = chipT(kend - 1 + 2 * smax), wa = 0, wb = 0;
+        while (ma >= clen) { ma -= clen; ++wa; }
+        while (mb >= clen) { mb -= clen; ++wb; }
+        rinfo[tid] = make_int4(wa * nedge + (int)rank[ma], wb * nedge + (int)rank[mb], (int)code[mb], 0);
+    }
+    if (tid < 32 * LUTPOS) {
+        const int idx = tid & 31, pos = tid >> 5;
+        const int cs_ = kCos32[idx], sn_ = kSin32[idx];
+        uint2 v;
+        if (DTYPE == 2) {   // bytes [c,-s] -> I ; [s,c] -> Q for one IQ sample
+            v.x = ((unsigned)(cs_ & 0xFF) | ((unsigned)((-sn_) & 0xFF) << 8)) << (16 * pos);
+            v.y = ((unsigned)(sn_ & 0xFF) | ((unsigned)(cs_ & 0xFF) << 8)) << (16 * pos);
+        } else {
+            v.x = (unsigned)(cs_ & 0xFF) << (8 * pos);
+            v.y = (unsigned)(sn_ & 0xFF) << (8 * pos);
+        }
+        lut[tid] = v;
+    }
+    // constant parts of the prefix image: row 0 and the closing column
+    for (int x = tid; x < RS; x += 256) loc[x] = make_int2(0, 0);
+    if (tid < LSP) loc[tid * RS + 256] = make_int2(0, 0);
+    for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
+    __syncthreads();
+
+    const bool flip = u.kflip < n;
+    const unsigned long long ps = u.ps_fx;
+    const unsigned long long phi0 = u.phi_fx + ((!flip && (u.neg & 1)) ? GC_FX_BIAS : 0ULL);
+    const bool pm1 = c.pm1 != 0;
+    unsigned accI[NTAP], accQ[NTAP], finI = 0, finQ = 0;
+    int toff[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) {
+        accI[t] = 0;
+        accQ[t] = 0;
+        toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
+    }
+    bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
+    auto edge_js = [&](int ed, int w) -> int {          // start sample of the chip the list entry names
+        const int m = (int)(short)(ed & 0xFFFF) + w * clen;
+        int js = (int)ceil(((double)m - cs) * inv);
+        if (js < 1) js = 1;
+        for (int it = 0; it < 8 && js > 1 && chipT(js - 1) >= m; it++) js--;
+        for (int it = 0; it < 8 && chipT(js) < m; it++) js++;
+        return js;
+    };
+    auto edge_load = [&](int q, int *w) -> int {
+        *w = 0;
+        while (q >= nedge) { q -= nedge; ++*w; }
+        return edges[q];
+    };
+
+    for (int r = 0; r < nround; r++) {
+        if (r + 1 < nround) load_round(r + 1, vnext);
+        const int4 ri = rinfo[r];
+        int q = ri.x + tid, ew = 0, ed = 0;
+        const int q1 = (ablate & 1) ? 0 : ri.y;
+        if (q < q1) ed = edge_load(q, &ew);            // in flight during the mixing phase
+        busy = busy || (ri.x + wv * 64 < q1);
+        const int kl = klo + r * RSAMP;
+
+        // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
+        int aI = 0, aQ = 0;
+        auto run = [&](auto flip_tag) {
+            constexpr bool FLIP = decltype(flip_tag)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int gl = tid * NIT + it, g = g0 + r * RGRP + gl;
+                uint4 v = vdata[it];
+                const int kb = kl + gl * SPG;
+                const bool edge = kb < 0 || kb + SPG > n || g >= G;
+                if (__ballot(edge) != 0ULL) {
+                    if (edge) {                         // blank the samples outside [0, n)
+                        unsigned m[4];
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            m[d] = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                const int k = kb + (d * 4 + b) / DTYPE;
+                                if (k >= 0 && k < n && g < G) m[d] |= 0xFFu << (8 * b);
+                            }
+                        }
+                        v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+                    }
+                }
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
+#pragma unroll
+                for (int i = 0; i < SPG; i++) {
+                    unsigned long long ph = phi;
+                    if (FLIP) ph += (((kb + i < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
+                    const int pos = DTYPE == 2 ? (i & 1) : (i & 3);
+                    const uint2 l = lut[32 * pos + (int)(ph >> 59)];
+                    const unsigned wd = w[DTYPE == 2 ? i >> 1 : i >> 2];
+                    aI = __builtin_amdgcn_sdot4((int)wd, (int)l.x, aI, false);
+                    aQ = __builtin_amdgcn_sdot4((int)wd, (int)l.y, aQ, false);
+                    const int p = it * SPG + i + 1;
+                    if (p < LSP) loc[p * RS + tid] = make_int2(aI, aQ);
+                    phi += ps;
+                }
+            }
+        };
+        if (!(ablate & 2)) { if (flip) run(std::true_type{}); else run(std::false_type{}); }
+        const int sI = wave_scan(aI), sQ = wave_scan(aQ);
+        if (lane == 63) wtot[wv] = make_int2(sI, sQ);
+        GC_STAMP(3);
+        __syncthreads();
+        GC_STAMP(4);
+        {   // sums in front of this lane's span: lanes of this wave, then the waves in front
+            int bi = sI - aI, bq = sQ - aQ, ti = 0, tq = 0;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+                const int2 t = wtot[w4];
+                if (w4 < wv) { bi += t.x; bq += t.y; }
+                ti += t.x; tq += t.y;
+            }
+            lbase[tid] = make_int2(bi, bq);
+            if (tid == 0) lbase[256] = make_int2(ti, tq);
+            finI += (unsigned)ri.z * (unsigned)ti;          // c_b P(S), the term of the round's last chip
+            finQ += (unsigned)ri.z * (unsigned)tq;
+        }
+        __syncthreads();
+
+        // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
+        const int roff = r * RSAMP;
+        while (q < q1) {
+            const int js = edge_js(ed, ew) - roff;
+            const int dd = ed >> 16;
+#pragma unroll
+            for (int t = 0; t < NTAP; t++) {
+                if (t < ntap) {
+                    int ee = js - toff[t];
+                    ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
+                    const int col = ee / LSP, row = ee % LSP;
+                    const int2 a = loc[row * RS + col], b = lbase[col];
+                    const unsigned pI = (unsigned)(a.x + b.x), pQ = (unsigned)(a.y + b.y);
+                    if (pm1) {                          // d = +-2: add or subtract, doubled at the end
+                        const unsigned sg = (unsigned)(dd >> 31);
+                        accI[t] += (pI ^ sg) - sg;
+                        accQ[t] += (pQ ^ sg) - sg;
+                    } else {
+                        accI[t] += (unsigned)dd * pI;
+                        accQ[t] += (unsigned)dd * pQ;
+                    }
+                }
+            }
+            q += 256;
+            if (q < q1) ed = edge_load(q, &ew);
+        }
+        if (r + 1 < nround) {
+            __syncthreads();                            // look-ups done before the image is rewritten
+#pragma unroll
+            for (int it = 0; it < NIT; it++) vdata[it] = vnext[it];
+        }
+    }
+    GC_STAMP(5);
+
+    // wavefront then workgroup reduction (waves without an edge leave red[] at its initial zero)
+    if (busy) {
+#pragma unroll
+        for (int t = 0; t < NTAP; t++) {
+            const int si = wave_sum63((int)accI[t]), sq = wave_sum63((int)accQ[t]);
+            if (lane == 63) {
+                red[wv * 2 * NTAP + t] = si;
+                red[wv * 2 * NTAP + NTAP + t] = sq;
+            }
+        }
+    }
+    __syncthreads();
+    GC_STAMP(6);
+    if (tid < ntap) {
+        unsigned si = 0, sq = 0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) {
+            si += (unsigned)red[w4 * 2 * NTAP + tid];
+            sq += (unsigned)red[w4 * 2 * NTAP + NTAP + tid];
+        }
+        if (pm1) { si *= 2u; sq *= 2u; }
+        pout[tid] = (int)(si + finI);
+        pout[ntap_stride + tid] = (int)(sq + finQ);
+    }
+#ifdef GC_TRK_TRACE
+    if (tr) { tr[7] = __builtin_readcyclecounter(); tr[9] = wall_clock64(); }
+#endif
 }
 
 // Sums the segment partials of every (channel, epoch) into the correlator
@@ -424,7 +788,35 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(const int *__restrict__
     }
 }
 
-int g_trk_nit = 0;      // groups per lane per segment workgroup (2, 4 or 8); 0 = not yet chosen
+int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8); 0 = not yet chosen
+int g_trk_algo = 0;     // 1 = prefix-sum form (default), 2 = replica form (GNSSCORR_TRK_ALGO=replica)
+
+// rounds per workgroup of the prefix-sum form: a whole period when it fits 16 rounds
+int trk_ps_rounds(int dtype, int max_n, int nit)
+{
+    const int groups = (15 + max_n * dtype + 15) / 16 + 1;
+    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
+    const int nseg = (rounds + 15) / 16;
+    return (rounds + nseg - 1) / nseg;
+}
+
+template <int DTYPE, int NTAP, int NIT>
+int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+                   int nseg, int ntap_stride, int ntap_lo, int max_n)
+{
+    const int lds = PsLayout<DTYPE, NIT>::bytes(NTAP);
+    const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
+    static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
+    if (lds > 64 * 1024)
+        GC_HIP(hipFuncSetAttribute((const void *)trk_corr_ps_kernel<DTYPE, NTAP, NIT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
+    if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
+    hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), lds, st, chan, unit,
+                       partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
+    GC_HIP(hipGetLastError());
+    return 0;
+}
 
 template <int DTYPE, int NTAP, int NIT>
 int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
@@ -451,6 +843,13 @@ template <int DTYPE, int NTAP>
 int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
                     int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
 {
+    if (g_trk_algo == 1) {
+        if (g_trk_nit == 1 || DTYPE == 1)
+            return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+        if (g_trk_nit == 4)
+            return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 4>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+        return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+    }
     switch (g_trk_nit) {
     default: return launch_corr<DTYPE, NTAP, 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
     case 8: return launch_corr<DTYPE, NTAP, 8>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
@@ -476,9 +875,15 @@ int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, 
 void trk_pick_nit()
 {
     if (g_trk_nit) return;
+    const char *a = getenv("GNSSCORR_TRK_ALGO");
+    g_trk_algo = (a && a[0] == 'r') ? 2 : 1;
     const char *e = getenv("GNSSCORR_TRK_NIT");
     g_trk_nit = e ? atoi(e) : 2;
-    if (g_trk_nit != 2 && g_trk_nit != 4 && g_trk_nit != 8) g_trk_nit = 2;
+    if (g_trk_algo == 1) {
+        if (g_trk_nit != 1 && g_trk_nit != 2 && g_trk_nit != 4) g_trk_nit = 2;
+    } else {
+        if (g_trk_nit != 2 && g_trk_nit != 4 && g_trk_nit != 8) g_trk_nit = 2;
+    }
 }
 
 }  // namespace
@@ -487,7 +892,10 @@ int gc_trk_nseg(int dtype, int max_n)
 {
     trk_pick_nit();
     const int groups = (15 + max_n * dtype + 15) / 16 + 1;
-    return (groups + 256 * g_trk_nit - 1) / (256 * g_trk_nit);
+    // real (1-byte) samples carry 16 running sums per group: one group per lane keeps the LDS image small
+    const int nit = (g_trk_algo == 1 && dtype == 1) ? 1 : g_trk_nit;
+    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
+    return g_trk_algo == 1 ? (rounds + 15) / 16 : rounds;
 }
 
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,

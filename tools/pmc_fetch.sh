@@ -12,6 +12,6 @@ for f in glob.glob("gpurun_out/pmc_f_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         m=re.search(r'(\w+_kernel)',r["Kernel_Name"]); k=m.group(1) if m else r["Kernel_Name"][:20]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k in ("trk_corr_kernel",):
+    for k in [x for x in agg if x.startswith("trk_corr")]:
         for c,v in agg[k].items(): print(k,c,"%.5g"%(sum(v)/len(v)))
 PY
