@@ -489,8 +489,9 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
                                                           int ntap_stride, int ntap_lo, int max_n, int rpw,
                                                           int ablate)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = PsLayout<DTYPE, NIT>;
+    // static, so that every LDS address is a compile-time offset
+    __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
     constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, RS = L::RS;
     const int tid = threadIdx.x;
     const int per_epoch = nch * nseg;
@@ -691,20 +692,23 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         __syncthreads();
 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
+        // (taps past ntap repeat tap 0 and are never written out; the +-1 code variant adds or
+        // subtracts and doubles at the end, the general one multiplies by the step)
         const int roff = r * RSAMP;
-        while (q < q1) {
-            const int js = edge_js(ed, ew) - roff;
-            const int dd = ed >> 16;
+        auto lookups = [&](auto pm1_tag) {
+            constexpr bool PM1 = decltype(pm1_tag)::value;
+            while (q < q1) {
+                const int js = edge_js(ed, ew) - roff;
+                const int dd = ed >> 16;
+                const unsigned sg = (unsigned)(dd >> 31);
 #pragma unroll
-            for (int t = 0; t < NTAP; t++) {
-                if (t < ntap) {
+                for (int t = 0; t < NTAP; t++) {
                     int ee = js - toff[t];
                     ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
                     const int col = ee / LSP, row = ee % LSP;
                     const int2 a = loc[row * RS + col], b = lbase[col];
                     const unsigned pI = (unsigned)(a.x + b.x), pQ = (unsigned)(a.y + b.y);
-                    if (pm1) {                          // d = +-2: add or subtract, doubled at the end
-                        const unsigned sg = (unsigned)(dd >> 31);
+                    if (PM1) {
                         accI[t] += (pI ^ sg) - sg;
                         accQ[t] += (pQ ^ sg) - sg;
                     } else {
@@ -712,10 +716,11 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
                         accQ[t] += (unsigned)dd * pQ;
                     }
                 }
+                q += 256;
+                if (q < q1) ed = edge_load(q, &ew);
             }
-            q += 256;
-            if (q < q1) ed = edge_load(q, &ew);
-        }
+        };
+        if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
         if (r + 1 < nround) {
             __syncthreads();                            // look-ups done before the image is rewritten
 #pragma unroll
@@ -804,15 +809,12 @@ template <int DTYPE, int NTAP, int NIT>
 int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
                    int nseg, int ntap_stride, int ntap_lo, int max_n)
 {
-    const int lds = PsLayout<DTYPE, NIT>::bytes(NTAP);
+    static_assert(PsLayout<DTYPE, NIT>::bytes(NTAP) <= 64 * 1024, "static LDS image");
     const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
     static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
-    if (lds > 64 * 1024)
-        GC_HIP(hipFuncSetAttribute((const void *)trk_corr_ps_kernel<DTYPE, NTAP, NIT>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
     if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
-    hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), lds, st, chan, unit,
+    hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), 0, st, chan, unit,
                        partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
     GC_HIP(hipGetLastError());
     return 0;
@@ -846,8 +848,6 @@ int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, i
     if (g_trk_algo == 1) {
         if (g_trk_nit == 1 || DTYPE == 1)
             return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
-        if (g_trk_nit == 4)
-            return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 4>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
         return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
     }
     switch (g_trk_nit) {
@@ -880,7 +880,7 @@ void trk_pick_nit()
     const char *e = getenv("GNSSCORR_TRK_NIT");
     g_trk_nit = e ? atoi(e) : 2;
     if (g_trk_algo == 1) {
-        if (g_trk_nit != 1 && g_trk_nit != 2 && g_trk_nit != 4) g_trk_nit = 2;
+        if (g_trk_nit != 1 && g_trk_nit != 2) g_trk_nit = 2;
     } else {
         if (g_trk_nit != 2 && g_trk_nit != 4 && g_trk_nit != 8) g_trk_nit = 2;
     }

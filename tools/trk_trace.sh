@@ -18,7 +18,7 @@ span=(t[:,9].max()-t[:,8].min())/100e6*1e3
 print("kernel span from stamps: %.3f ms"%span)
 # concurrency: average number of sampled WGs alive * 31
 ev=np.concatenate([np.stack([t[:,8],np.ones(len(t))],1),np.stack([t[:,9],-np.ones(len(t))],1)]); ev=ev[np.argsort(ev[:,0],kind="stable")]
-alive=np.cumsum(ev[:,1]); dtv=np.diff(ev[:,0]); print("mean concurrent WGs (x31): %.0f"%((alive[:-1]*dtv).sum()/dtv.sum()*31))
+alive=np.cumsum(ev[:,1]); dtv=np.diff(ev[:,0]); print("mean concurrent WGs (x7): %.0f"%((alive[:-1]*dtv).sum()/dtv.sum()*7))
 
 
 print(json.load(open("gpurun_out/trk_trace.json"))["kernels_ms_per_step"])
