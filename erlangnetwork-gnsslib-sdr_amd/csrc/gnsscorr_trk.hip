@@ -539,14 +539,28 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
     const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
     const int wv = tid >> 6, lane = tid & 63;
+    // A round whose 16-byte groups do not run over the end of the ring (all but one per ring
+    // revolution) is loaded from a wave-uniform base plus the lane's offset, groups past the period's
+    // end included: they stay inside the ring and are blanked below.
     auto load_round = [&](int r, uint4 *dst) {
+        uint64_t rb = u.a_al + (uint64_t)(g0 + r * RGRP) * 16;
+        if (rb >= ringbytes) rb -= ringbytes;
+        if (rb + (uint64_t)RGRP * 16 <= ringbytes) {
+            const gc_gptr_i8 base = ring + rb;
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int g = g0 + r * RGRP + tid * NIT + it;
-            uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
-            if (addr >= ringbytes) addr -= ringbytes;
-            const gc_u4v t4 = *(gc_gptr_u4)(ring + addr);
-            dst[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+            for (int it = 0; it < NIT; it++) {
+                const gc_u4v t4 = *(gc_gptr_u4)(base + (unsigned)(tid * NIT + it) * 16u);
+                dst[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int g = g0 + r * RGRP + tid * NIT + it;
+                uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
+                if (addr >= ringbytes) addr -= ringbytes;
+                const gc_u4v t4 = *(gc_gptr_u4)(ring + addr);
+                dst[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+            }
         }
     };
     uint4 vdata[NIT], vnext[NIT];
@@ -604,6 +618,9 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         accQ[t] = 0;
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
     }
+    // carrier phase of this lane's first sample of the round; a round further on it is RSAMP steps later
+    unsigned long long phir = phi0 + (unsigned long long)(long long)(klo + tid * LSP) * ps;
+    const unsigned long long psr = (unsigned long long)RSAMP * ps;
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
     auto edge_js = [&](int ed, int w) -> int {          // start sample of the chip the list entry names
         const int m = (int)(short)(ed & 0xFFFF) + w * clen;
@@ -630,31 +647,35 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
 
         // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
         int aI = 0, aQ = 0;
+        // only the first and the last round of a period hold samples outside [0, n)
+        const bool ragged = kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G;
         auto run = [&](auto flip_tag) {
             constexpr bool FLIP = decltype(flip_tag)::value;
+            unsigned long long phi = phir;              // phase of the lane's first sample this round
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int gl = tid * NIT + it, g = g0 + r * RGRP + gl;
                 uint4 v = vdata[it];
                 const int kb = kl + gl * SPG;
-                const bool edge = kb < 0 || kb + SPG > n || g >= G;
-                if (__ballot(edge) != 0ULL) {
-                    if (edge) {                         // blank the samples outside [0, n)
-                        unsigned m[4];
+                if (ragged) {
+                    const bool edge = kb < 0 || kb + SPG > n || g >= G;
+                    if (__ballot(edge) != 0ULL) {
+                        if (edge) {                     // blank the samples outside [0, n)
+                            unsigned m[4];
 #pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            m[d] = 0;
+                            for (int d = 0; d < 4; d++) {
+                                m[d] = 0;
 #pragma unroll
-                            for (int b = 0; b < 4; b++) {
-                                const int k = kb + (d * 4 + b) / DTYPE;
-                                if (k >= 0 && k < n && g < G) m[d] |= 0xFFu << (8 * b);
+                                for (int b = 0; b < 4; b++) {
+                                    const int k = kb + (d * 4 + b) / DTYPE;
+                                    if (k >= 0 && k < n && g < G) m[d] |= 0xFFu << (8 * b);
+                                }
                             }
+                            v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
                         }
-                        v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
                     }
                 }
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
-                unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
 #pragma unroll
                 for (int i = 0; i < SPG; i++) {
                     unsigned long long ph = phi;
@@ -721,6 +742,7 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
+        phir += psr;
         if (r + 1 < nround) {
             __syncthreads();                            // look-ups done before the image is rewritten
 #pragma unroll
