@@ -84,6 +84,7 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     hipFree(ctx->dsumQ);  ctx->dsumQ = nullptr;
     hipFree(ctx->dpartial); ctx->dpartial = nullptr;
     hipFree(ctx->dunit); ctx->dunit = nullptr;
+    hipFree(ctx->drounds); ctx->drounds = nullptr;
     ctx->plan_cap = 0;
 }
 
@@ -373,6 +374,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
         if (s > ctx->nseg) ctx->nseg = s;
     }
     GC_HIP(hipMalloc((void **)&ctx->dpartial, sizeof(int) * units * ctx->nseg * 2 * ctx->ntap));
+    GC_HIP(hipMalloc((void **)&ctx->drounds, sizeof(GcRound) * units * ctx->nseg * GC_MAXR));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -408,7 +410,8 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     GcTrkPlan *dplan = ctx->dplan2[slot];
     {
         GcTimed t(ctx, "trk_expand");
-        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch);
+        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch, ctx->drounds,
+                                  ctx->nseg, ctx->max_n);
         if (rc) return rc;
     }
     if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));
@@ -431,7 +434,7 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
-        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit, ctx->dpartial, ctx->nch, nepoch, ctx->nseg,
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit, ctx->drounds, ctx->dpartial, ctx->nch, nepoch, ctx->nseg,
                                 ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }

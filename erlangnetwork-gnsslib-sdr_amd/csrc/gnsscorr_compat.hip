@@ -24,6 +24,7 @@ struct GcOnce {
     GcTrkUnit *unit = nullptr;
     double *out = nullptr;                           // 4*GNSSCORR_MAXTAPS: corrI, corrQ, sumI, sumQ
     int *partial = nullptr;  int partial_cap = 0;    // nseg*2*ntap
+    GcRound *rounds = nullptr;  int rounds_cap = 0;  // nseg*GC_MAXR
 };
 static GcOnce g_once;
 
@@ -92,9 +93,15 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
         GC_HIP(hipMalloc((void **)&g_once.partial, sizeof(int) * nseg * 2 * c.ntap));
         g_once.partial_cap = nseg * 2 * c.ntap;
     }
-    rc = gc_launch_trk_expand(ctx->stream, g_once.chan, g_once.plan, g_once.unit, nullptr, 1, 1);
+    if (nseg > g_once.rounds_cap) {
+        if (g_once.rounds) hipFree(g_once.rounds);
+        g_once.rounds = nullptr; g_once.rounds_cap = 0;
+        GC_HIP(hipMalloc((void **)&g_once.rounds, sizeof(GcRound) * nseg * GC_MAXR));
+        g_once.rounds_cap = nseg;
+    }
+    rc = gc_launch_trk_expand(ctx->stream, g_once.chan, g_once.plan, g_once.unit, nullptr, 1, 1, g_once.rounds, nseg, n);
     if (rc) return rc;
-    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.partial, 1, 1, nseg, c.ntap, dtype,
+    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.rounds, g_once.partial, 1, 1, nseg, c.ntap, dtype,
                             c.ntap, n, c.smax);
     if (rc) return rc;
     rc = gc_launch_trk_finish(ctx->stream, g_once.partial, g_once.out, g_once.out + GNSSCORR_MAXTAPS,

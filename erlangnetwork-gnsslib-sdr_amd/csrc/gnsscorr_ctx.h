@@ -60,6 +60,7 @@ struct gnsscorr_ctx {
     hipEvent_t ev_plan[2] = {nullptr, nullptr};    // plan of slot s finished
     hipEvent_t ev_used[2] = {nullptr, nullptr};    // expand consumed slot s
     GcTrkUnit *dunit = nullptr;
+    GcRound *drounds = nullptr;    // [unit][nseg][GC_MAXR]
     size_t plan_cap = 0;
     double *dcorrI = nullptr, *dcorrQ = nullptr, *dsumI = nullptr, *dsumQ = nullptr;
     int *dnsamp = nullptr;

@@ -136,12 +136,17 @@ struct GcAcqRow {
 int gc_fail_hip(hipError_t e, const char *what, const char *file, int line);
 int gc_fail(int code, const char *fmt, ...);
 
+// One round of the prefix-sum correlator (gnsscorr_trk.hip): the chip edges [q0, q1) its samples can
+// touch, in the numbering period * nedge + list index, and the value of its last chip.
+#define GC_MAXR 16
+struct GcRound { int q0, q1, clast, pad; };
+
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch);
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
-                         int *nsamp_out, int nch, int nepoch);
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch,
+                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n);
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch,
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max);
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
                          double *sumQ, int nch, int nepoch, int nseg, int ntap);

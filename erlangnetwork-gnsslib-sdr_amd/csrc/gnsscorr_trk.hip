@@ -85,6 +85,18 @@ __global__ void trk_plan_kernel(const GcChan *__restrict__ chan, const GcTrkStat
     state_out[ch] = s;
 }
 
+// rounds per workgroup of the prefix-sum correlator: a whole period when it fits GC_MAXR rounds
+__host__ __device__ inline int trk_ps_rounds(int dtype, int max_n, int nit)
+{
+    const int groups = (15 + max_n * dtype + 15) / 16 + 1;
+    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
+    const int nseg = (rounds + GC_MAXR - 1) / GC_MAXR;
+    return (rounds + nseg - 1) / nseg;
+}
+// groups per lane and round: real (1-byte) samples carry 16 running sums per group, one group keeps
+// the LDS image small
+__host__ __device__ inline int trk_ps_nit(int dtype, int nit) { return dtype == 1 ? 1 : nit; }
+
 // ---------------------------------------------------------------------------
 // per-unit constants
 // ---------------------------------------------------------------------------
@@ -92,7 +104,7 @@ __global__ void trk_plan_kernel(const GcChan *__restrict__ chan, const GcTrkStat
 // otherwise each recompute (ring offset, NCO start values).
 __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
                                   GcTrkUnit *__restrict__ unit, int *__restrict__ nsamp_out, int nch,
-                                  int nepoch)
+                                  int nepoch, GcRound *__restrict__ rounds, int nseg, int max_n, int nit)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nch * nepoch) return;
@@ -111,6 +123,34 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     u.inv_ci = 1.0 / u.ci;
     unit[i] = u;
     if (nsamp_out) nsamp_out[i] = p.n;
+
+    // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel): round r of workgroup
+    // seg covers samples [kl, kl + rsamp) of the period and can touch the chips T(first sample) ..
+    // T(last sample + 2 smax); rank[] turns those into positions in the code's edge list
+    if (!rounds || !(p.n > 0 && p.n <= max_n && u.ci > 0.0 && u.ci <= 4.0)) return;
+    const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
+    const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
+    const unsigned short *rank = (const unsigned short *)(c.code + 1024);
+    for (int seg = 0; seg < nseg; seg++) {
+        const int g0 = seg * rgrp * rpw;
+        if (g0 >= u.G) break;
+        const int klo = (g0 * 16 - u.head) / c.dtype;
+        for (int r = 0; r < rpw && g0 + r * rgrp < u.G; r++) {
+            const int kl = klo + r * rsamp;
+            const int kfirst = kl > 0 ? kl : 0;
+            const int kend = (kl + rsamp < p.n ? kl + rsamp : p.n);
+            int ma = (int)__fma_rn((double)kfirst, u.ci, u.cs);
+            int mb = (int)__fma_rn((double)(kend - 1 + 2 * c.smax), u.ci, u.cs), wa = 0, wb = 0;
+            while (ma >= c.clen) { ma -= c.clen; ++wa; }
+            while (mb >= c.clen) { mb -= c.clen; ++wb; }
+            GcRound ro;
+            ro.q0 = wa * c.nedge + (int)rank[ma];
+            ro.q1 = wb * c.nedge + (int)rank[mb];
+            ro.clast = (int)c.code[mb];
+            ro.pad = 0;
+            rounds[((size_t)i * nseg + seg) * GC_MAXR + r] = ro;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -460,12 +500,11 @@ struct PsLayout {
     static constexpr int RGRP = 256 * NIT;                      // groups per round
     static constexpr int RSAMP = 256 * LSP;                     // samples per round
     static constexpr int RS = 256 + 1;                          // + closing column (P = total there)
-    static constexpr int MAXR = 16;                             // rounds per workgroup, at most
+    static constexpr int MAXR = GC_MAXR;                        // rounds per workgroup, at most
     static constexpr int LUTPOS = DTYPE == 2 ? 2 : 4;
     static constexpr int LUT_BYTES = 32 * 8 * LUTPOS;
-    static constexpr int WT_OFF = LUT_BYTES;                    // wtot[4] int2
-    static constexpr int RI_OFF = WT_OFF + 32;                  // rinfo[MAXR] int4
-    static constexpr int LB_OFF = RI_OFF + MAXR * 16;
+    static constexpr int WT_OFF = LUT_BYTES;                    // wpre[2][8] int2 (two rounds in flight)
+    static constexpr int LB_OFF = WT_OFF + 128;
     static constexpr int LOC_OFF = LB_OFF + ((RS * 8 + 15) & ~15);
     static constexpr int RED_OFF = LOC_OFF + ((LSP * RS * 8 + 15) & ~15);
     static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
@@ -483,8 +522,9 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 }
 
 template <int DTYPE, int NTAP, int NIT>
-__global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 8 : 4, 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
                                                           const GcTrkUnit *__restrict__ unit,
+                                                          const GcRound *__restrict__ rounds,
                                                           int *__restrict__ partial, int nch, int nepoch, int nseg,
                                                           int ntap_stride, int ntap_lo, int max_n, int rpw,
                                                           int ablate)
@@ -501,8 +541,8 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
     if (e >= nepoch) return;
 #ifdef GC_TRK_TRACE
     unsigned long long *tr = nullptr;
-    if (tid == 0 && (blockIdx.x % 7) == 0 && blockIdx.x / 7 < GC_TRACE_N) {
-        tr = gc_trk_trace + (blockIdx.x / 7) * 12;
+    if ((tid == 0 || tid == 192) && (blockIdx.x % 15) == 0 && blockIdx.x / 15 < GC_TRACE_N / 2) {
+        tr = gc_trk_trace + ((blockIdx.x / 15) * 2 + (tid != 0)) * 12;
         tr[8] = wall_clock64();
         tr[11] = blockIdx.x;
     }
@@ -530,8 +570,7 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
 
     constexpr int LUTPOS = L::LUTPOS;
     uint2 *lut = reinterpret_cast<uint2 *>(smem);
-    int2 *wtot = reinterpret_cast<int2 *>(smem + L::WT_OFF);          // [4] per-wave totals
-    int4 *rinfo = reinterpret_cast<int4 *>(smem + L::RI_OFF);         // [MAXR] {q0, q1, last chip, -}
+    int *wpre = reinterpret_cast<int *>(smem + L::WT_OFF);            // [2][8][2]: sums of the waves in front
     int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF);         // [256 + 1]
     int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [LSP][RS]
     int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x 2*NTAP
@@ -563,30 +602,16 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
             }
         }
     };
-    uint4 vdata[NIT], vnext[NIT];
-    load_round(0, vdata);
-    GC_STAMP(2);
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
     // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
     // T(j) = trunc(fma(j, ci, cs)).  Only chips at which the code changes value matter; they are
     // numbered q = period * nedge + list index, and rank[] converts a chip number into that
-    // numbering.  Lane r prepares round r: the edges [q0, q1) its samples can touch and its last chip.
+    // numbering; trk_expand prepared, per round, the edges [q0, q1) its samples can touch.
     const gc_gptr_i8 code = (gc_gptr_i8)c.code;
-    const unsigned short __attribute__((address_space(1))) *rank =
-        (const unsigned short __attribute__((address_space(1))) *)(code + 1024);
     const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)(code + 3072);
     const int nedge = c.nedge;
     auto chipT = [&](int j) -> int { return (int)__fma_rn((double)j, ci, cs); };
-    if (tid < nround) {
-        const int kl = klo + tid * RSAMP;
-        const int kfirst = kl > 0 ? kl : 0;
-        const int kend = (kl + RSAMP < n ? kl + RSAMP : n);       // one past the round's last real sample
-        int ma = chipT(kfirst), mb = chipT(kend - 1 + 2 * smax), wa = 0, wb = 0;
-        while (ma >= clen) { ma -= clen; ++wa; }
-        while (mb >= clen) { mb -= clen; ++wb; }
-        rinfo[tid] = make_int4(wa * nedge + (int)rank[ma], wb * nedge + (int)rank[mb], (int)code[mb], 0);
-    }
     if (tid < 32 * LUTPOS) {
         const int idx = tid & 31, pos = tid >> 5;
         const int cs_ = kCos32[idx], sn_ = kSin32[idx];
@@ -604,6 +629,7 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
     for (int x = tid; x < RS; x += 256) loc[x] = make_int2(0, 0);
     if (tid < LSP) loc[tid * RS + 256] = make_int2(0, 0);
     for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
+    if (tid < 32) wpre[tid] = 0;
     __syncthreads();
 
     const bool flip = u.kflip < n;
@@ -621,6 +647,7 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
     // carrier phase of this lane's first sample of the round; a round further on it is RSAMP steps later
     unsigned long long phir = phi0 + (unsigned long long)(long long)(klo + tid * LSP) * ps;
     const unsigned long long psr = (unsigned long long)RSAMP * ps;
+    const GcRound *myrounds = rounds + (((size_t)ch * nepoch + e) * nseg + seg) * GC_MAXR;
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
     auto edge_js = [&](int ed, int w) -> int {          // start sample of the chip the list entry names
         const int m = (int)(short)(ed & 0xFFFF) + w * clen;
@@ -636,13 +663,15 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         return edges[q];
     };
 
-    for (int r = 0; r < nround; r++) {
+    auto round = [&](int r, uint4 *vdata, uint4 *vnext) {
+        if (r == 1) GC_STAMP(2);
         if (r + 1 < nround) load_round(r + 1, vnext);
-        const int4 ri = rinfo[r];
-        int q = ri.x + tid, ew = 0, ed = 0;
-        const int q1 = (ablate & 1) ? 0 : ri.y;
+        const GcRound ro = myrounds[r];
+        const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast;
+        int q = rq0 + tid, ew = 0, ed = 0;
+        const int q1 = (ablate & 1) ? 0 : rq1;
         if (q < q1) ed = edge_load(q, &ew);            // in flight during the mixing phase
-        busy = busy || (ri.x + wv * 64 < q1);
+        busy = busy || (rq0 + wv * 64 < q1);
         const int kl = klo + r * RSAMP;
 
         // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
@@ -693,24 +722,32 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         };
         if (!(ablate & 2)) { if (flip) run(std::true_type{}); else run(std::false_type{}); }
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
-        if (lane == 63) wtot[wv] = make_int2(sI, sQ);
-        GC_STAMP(3);
-        __syncthreads();
-        GC_STAMP(4);
-        {   // sums in front of this lane's span: lanes of this wave, then the waves in front
-            int bi = sI - aI, bq = sQ - aQ, ti = 0, tq = 0;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; w4++) {
-                const int2 t = wtot[w4];
-                if (w4 < wv) { bi += t.x; bq += t.y; }
-                ti += t.x; tq += t.y;
+        // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
+        // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
+        int *wp = wpre + (r & 1) * 16;
+        {
+            const int tI = __builtin_amdgcn_readlane(sI, 63), tQ = __builtin_amdgcn_readlane(sQ, 63);
+            const int slot = wv + 1 + (lane - 60);
+            if (lane >= 60 && slot <= 4) {
+                atomicAdd(&wp[2 * slot], tI);
+                atomicAdd(&wp[2 * slot + 1], tQ);
             }
-            lbase[tid] = make_int2(bi, bq);
-            if (tid == 0) lbase[256] = make_int2(ti, tq);
-            finI += (unsigned)ri.z * (unsigned)ti;          // c_b P(S), the term of the round's last chip
-            finQ += (unsigned)ri.z * (unsigned)tq;
+        }
+        if (r == 1) GC_STAMP(3);
+        __syncthreads();
+        if (r == 1) GC_STAMP(4);
+        {   // sums in front of this lane's span: lanes of this wave, then the waves in front
+            const int2 pre = *reinterpret_cast<const int2 *>(&wp[2 * wv]);
+            const int2 tv = *reinterpret_cast<const int2 *>(&wp[8]);
+            lbase[tid] = make_int2(sI - aI + pre.x, sQ - aQ + pre.y);
+            if (tid == 0) lbase[256] = tv;
+            const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
+            finI += (unsigned)rlast * (unsigned)ti;         // c_b P(S), the term of the round's last chip
+            finQ += (unsigned)rlast * (unsigned)tq;
+            if (tid < 16) wpre[((r + 1) & 1) * 16 + tid] = 0;   // the other copy, for the next round
         }
         __syncthreads();
+        if (r == 1) GC_STAMP(5);
 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
         // (taps past ntap repeat tap 0 and are never written out; the +-1 code variant adds or
@@ -743,13 +780,16 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
         phir += psr;
-        if (r + 1 < nround) {
-            __syncthreads();                            // look-ups done before the image is rewritten
-#pragma unroll
-            for (int it = 0; it < NIT; it++) vdata[it] = vnext[it];
-        }
+        if (r == 1) GC_STAMP(6);
+        if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
+        if (r == 1) GC_STAMP(1);
+    };
+    uint4 vA[NIT], vB[NIT];
+    load_round(0, vA);
+    for (int r = 0; r < nround; r += 2) {
+        round(r, vA, vB);
+        if (r + 1 < nround) round(r + 1, vB, vA);
     }
-    GC_STAMP(5);
 
     // wavefront then workgroup reduction (waves without an edge leave red[] at its initial zero)
     if (busy) {
@@ -763,7 +803,6 @@ __global__ __launch_bounds__(256) void trk_corr_ps_kernel(const GcChan *__restri
         }
     }
     __syncthreads();
-    GC_STAMP(6);
     if (tid < ntap) {
         unsigned si = 0, sq = 0;
 #pragma unroll
@@ -818,18 +857,9 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(const int *__restrict__
 int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8); 0 = not yet chosen
 int g_trk_algo = 0;     // 1 = prefix-sum form (default), 2 = replica form (GNSSCORR_TRK_ALGO=replica)
 
-// rounds per workgroup of the prefix-sum form: a whole period when it fits 16 rounds
-int trk_ps_rounds(int dtype, int max_n, int nit)
-{
-    const int groups = (15 + max_n * dtype + 15) / 16 + 1;
-    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
-    const int nseg = (rounds + 15) / 16;
-    return (rounds + nseg - 1) / nseg;
-}
-
 template <int DTYPE, int NTAP, int NIT>
-int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
-                   int nseg, int ntap_stride, int ntap_lo, int max_n)
+int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial,
+                   int nch, int nepoch, int nseg, int ntap_stride, int ntap_lo, int max_n)
 {
     static_assert(PsLayout<DTYPE, NIT>::bytes(NTAP) <= 64 * 1024, "static LDS image");
     const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
@@ -837,7 +867,7 @@ int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, in
     const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
     if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
     hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), 0, st, chan, unit,
-                       partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
+                       rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
     GC_HIP(hipGetLastError());
     return 0;
 }
@@ -864,13 +894,13 @@ int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *
 }
 
 template <int DTYPE, int NTAP>
-int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch, int nepoch,
                     int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
 {
     if (g_trk_algo == 1) {
         if (g_trk_nit == 1 || DTYPE == 1)
-            return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
-        return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+            return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+        return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
     }
     switch (g_trk_nit) {
     default: return launch_corr<DTYPE, NTAP, 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
@@ -880,11 +910,11 @@ int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, i
 }
 
 template <int DTYPE>
-int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch, int nepoch,
                      int nseg, int ntap_stride, int ntap, int max_n, int smax_max)
 {
     // smallest instantiation that holds ntap accumulators; it serves (lo, NTAP]
-#define GC_LC(N, LO) return launch_corr_nit<DTYPE, N>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, LO, max_n, smax_max)
+#define GC_LC(N, LO) return launch_corr_nit<DTYPE, N>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, LO, max_n, smax_max)
     if (ntap <= 3)  GC_LC(3, 0);
     if (ntap <= 5)  GC_LC(5, 3);
     if (ntap <= 7)  GC_LC(7, 5);
@@ -915,9 +945,9 @@ int gc_trk_nseg(int dtype, int max_n)
     trk_pick_nit();
     const int groups = (15 + max_n * dtype + 15) / 16 + 1;
     // real (1-byte) samples carry 16 running sums per group: one group per lane keeps the LDS image small
-    const int nit = (g_trk_algo == 1 && dtype == 1) ? 1 : g_trk_nit;
+    const int nit = g_trk_algo == 1 ? trk_ps_nit(dtype, g_trk_nit) : g_trk_nit;
     const int rounds = (groups + 256 * nit - 1) / (256 * nit);
-    return g_trk_algo == 1 ? (rounds + 15) / 16 : rounds;
+    return g_trk_algo == 1 ? (rounds + GC_MAXR - 1) / GC_MAXR : rounds;
 }
 
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
@@ -930,26 +960,27 @@ int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *sta
 }
 
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
-                         int *nsamp_out, int nch, int nepoch)
+                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n)
 {
+    trk_pick_nit();
     const int total = nch * nepoch;
-    hipLaunchKernelGGL(trk_expand_kernel, dim3((total + 255) / 256), dim3(256), 0, st, chan, plan, unit, nsamp_out,
-                       nch, nepoch);
+    hipLaunchKernelGGL(trk_expand_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, plan, unit, nsamp_out,
+                       nch, nepoch, g_trk_algo == 1 ? rounds : (GcRound *)nullptr, nseg, max_n, g_trk_nit);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
 // One launch serves every channel whose (dtype, tap bucket) matches; callers
 // invoke it once per distinct dtype present in the channel set.
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch,
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch,
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max)
 {
     trk_pick_nit();
     if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_corr: tap offset %d samples (<= 64 supported)", smax_max);
     if (dtype == 2)
-        return launch_corr_taps<2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<2>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     if (dtype == 1)
-        return launch_corr_taps<1>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<1>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     return gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
 }
 
