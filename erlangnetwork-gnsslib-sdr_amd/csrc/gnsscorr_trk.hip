@@ -675,7 +675,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
         const int kl = klo + r * RSAMP;
 
         // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
-        int aI = 0, aQ = 0;
+        int aI = 0, aQ = 0, js = 0;
+        const int roff = r * RSAMP;
         // only the first and the last round of a period hold samples outside [0, n)
         const bool ragged = kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G;
         auto run = [&](auto flip_tag) {
@@ -721,6 +722,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
             }
         };
         if (!(ablate & 2)) { if (flip) run(std::true_type{}); else run(std::false_type{}); }
+        // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
+        if (q < q1) js = edge_js(ed, ew) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
         // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
         // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
@@ -752,11 +755,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
         // (taps past ntap repeat tap 0 and are never written out; the +-1 code variant adds or
         // subtracts and doubles at the end, the general one multiplies by the step)
-        const int roff = r * RSAMP;
         auto lookups = [&](auto pm1_tag) {
             constexpr bool PM1 = decltype(pm1_tag)::value;
             while (q < q1) {
-                const int js = edge_js(ed, ew) - roff;
                 const int dd = ed >> 16;
                 const unsigned sg = (unsigned)(dd >> 31);
 #pragma unroll
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                     }
                 }
                 q += 256;
-                if (q < q1) ed = edge_load(q, &ew);
+                if (q < q1) { ed = edge_load(q, &ew); js = edge_js(ed, ew) - roff; }
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
