@@ -493,6 +493,22 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
 //            reciprocal estimate, corrected against T itself), then per tap
 //            P = loc + lbase at the clamped sample position.
 // Accumulators stay in registers over the rounds; one reduction at the end.
+// cost[i] of the carrier LUT from immediates (no table load on the workgroup's critical path):
+// eight dwords of four int8 entries each
+__device__ __forceinline__ int lut_cos(int i)
+{
+    auto pk = [](int a, int b, int c, int d) -> unsigned {
+        return (unsigned)(a & 0xFF) | ((unsigned)(b & 0xFF) << 8) | ((unsigned)(c & 0xFF) << 16) | ((unsigned)(d & 0xFF) << 24);
+    };
+    const unsigned w0 = pk(32, 31, 30, 27), w1 = pk(23, 18, 12, 6), w2 = pk(0, -6, -12, -18), w3 = pk(-23, -27, -30, -31);
+    const unsigned w4 = pk(-32, -31, -30, -27), w5 = pk(-23, -18, -12, -6), w6 = pk(0, 6, 12, 18), w7 = pk(23, 27, 30, 31);
+    const int h = i >> 2;
+    const unsigned lo = (h & 2) ? ((h & 1) ? w3 : w2) : ((h & 1) ? w1 : w0);
+    const unsigned hi = (h & 2) ? ((h & 1) ? w7 : w6) : ((h & 1) ? w5 : w4);
+    const unsigned w = (h & 4) ? hi : lo;
+    return (int)(signed char)((w >> (8 * (i & 3))) & 0xFF);
+}
+
 template <int DTYPE, int NIT>
 struct PsLayout {
     static constexpr int SPG = 16 / DTYPE;                      // samples per 16-byte group
@@ -602,6 +618,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
             }
         }
     };
+    uint4 vA[NIT], vB[NIT];
+    load_round(0, vA);                                  // in flight while the tables are set up
+    GC_STAMP(2);
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
     // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
@@ -614,7 +633,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     auto chipT = [&](int j) -> int { return (int)__fma_rn((double)j, ci, cs); };
     if (tid < 32 * LUTPOS) {
         const int idx = tid & 31, pos = tid >> 5;
-        const int cs_ = kCos32[idx], sn_ = kSin32[idx];
+        const int cs_ = lut_cos(idx), sn_ = lut_cos((idx - 8) & 31);     // sin(i) = cos(i - 8)
         uint2 v;
         if (DTYPE == 2) {   // bytes [c,-s] -> I ; [s,c] -> Q for one IQ sample
             v.x = ((unsigned)(cs_ & 0xFF) | ((unsigned)((-sn_) & 0xFF) << 8)) << (16 * pos);
@@ -785,8 +804,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
         if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
         if (r == 1) GC_STAMP(1);
     };
-    uint4 vA[NIT], vB[NIT];
-    load_round(0, vA);
     for (int r = 0; r < nround; r += 2) {
         round(r, vA, vB);
         if (r + 1 < nround) round(r + 1, vB, vA);

@@ -10,7 +10,7 @@ t=np.load("gpurun_out/trk_trace.npy").astype(np.int64)
 for wv,name in ((0,"wave 0"),(1,"wave 3")):
     x=t[wv::2]; x=x[(x[:,7]>0)&(x[:,0]>0)&(x[:,2]>0)]
     print(name,"sampled",len(x),"WG lifetime cycles mean %.0f"%(x[:,7]-x[:,0]).mean(), "wall us %.2f"%((x[:,9]-x[:,8]).mean()/100))
-    seq=[("start->round1 begin",0,2),("A (mix+scan+atomics)",2,3),("barrier1",3,4),("lbase+barrier2",4,5),("B look-ups",5,6),("barrier3",6,1),("round1 end->kernel end",1,7)]
+    seq=[("prologue (start->round0)",0,10),("round0",10,2),("A (mix+scan+atomics)",2,3),("barrier1",3,4),("lbase+barrier2",4,5),("B look-ups",5,6),("barrier3",6,1),("rounds 2..",1,11),("reduce+store",11,7)]
     for n,a,b in seq:
         d=x[:,b]-x[:,a]; print("  %-24s mean %7.0f median %7.0f p90 %7.0f"%(n,d.mean(),np.median(d),np.percentile(d,90)))
 print(json.load(open("gpurun_out/trk_trace.json"))["kernels_ms_per_step"])
