@@ -79,12 +79,15 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     ctx->ahead_valid = false;
     hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
     hipFree(ctx->dcorrQ); ctx->dcorrQ = nullptr;
-    hipFree(ctx->dnsamp); ctx->dnsamp = nullptr;
     hipFree(ctx->dsumI);  ctx->dsumI = nullptr;
+    hipFree(ctx->dfinish); ctx->dfinish = nullptr;
     hipFree(ctx->dsumQ);  ctx->dsumQ = nullptr;
     hipFree(ctx->dpartial); ctx->dpartial = nullptr;
-    hipFree(ctx->dunit); ctx->dunit = nullptr;
-    hipFree(ctx->drounds); ctx->drounds = nullptr;
+    for (int i = 0; i < 2; i++) {
+        hipFree(ctx->dunit2[i]); ctx->dunit2[i] = nullptr;
+        hipFree(ctx->drounds2[i]); ctx->drounds2[i] = nullptr;
+        hipFree(ctx->dnsamp2[i]); ctx->dnsamp2[i] = nullptr;
+    }
     ctx->plan_cap = 0;
 }
 
@@ -362,19 +365,23 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     }
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
-    GC_HIP(hipMalloc((void **)&ctx->dunit, sizeof(GcTrkUnit) * units));
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
-    GC_HIP(hipMalloc((void **)&ctx->dnsamp, sizeof(int) * units));
     GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dsumQ, sizeof(double) * ctx->nch * ctx->ntap));
+    GC_HIP(hipMalloc((void **)&ctx->dfinish, sizeof(unsigned long long) * ctx->nch * GC_FINISH_SCRATCH));
+    GC_HIP(hipMemsetAsync(ctx->dfinish, 0, sizeof(unsigned long long) * ctx->nch * GC_FINISH_SCRATCH, ctx->stream));
     ctx->nseg = 1;
     for (int i = 0; i < ctx->nch; i++) {
         const int s = gc_trk_nseg(ctx->hchan[i].dtype, ctx->max_n);
         if (s > ctx->nseg) ctx->nseg = s;
     }
     GC_HIP(hipMalloc((void **)&ctx->dpartial, sizeof(int) * units * ctx->nseg * 2 * ctx->ntap));
-    GC_HIP(hipMalloc((void **)&ctx->drounds, sizeof(GcRound) * units * ctx->nseg * GC_MAXR));
+    for (int i = 0; i < 2; i++) {
+        GC_HIP(hipMalloc((void **)&ctx->dunit2[i], sizeof(GcTrkUnit) * units));
+        GC_HIP(hipMalloc((void **)&ctx->dnsamp2[i], sizeof(int) * units));
+        GC_HIP(hipMalloc((void **)&ctx->drounds2[i], sizeof(GcRound) * units * ctx->nseg * GC_MAXR));
+    }
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -387,7 +394,25 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     int rc = ensure_trk_buffers(ctx, nepoch);
     if (rc) return rc;
     // ---- planner: use the look-ahead plan if it matches, else plan now ----
+    // plan = the sequential NCO chain per channel, expand = the per-unit constants of that plan; both
+    // run on the planner stream into slot buffers, ev_plan[slot] marks them ready
     hipStream_t ps = ctx->stream2 ? ctx->stream2 : ctx->stream;
+    auto plan_into = [&](int s) -> int {
+        {
+            GcTimed t(ctx, "trk_plan", ps);
+            int r2 = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
+                                        ctx->dplan2[s], ctx->nch, nepoch);
+            if (r2) return r2;
+        }
+        {
+            GcTimed t(ctx, "trk_expand", ps);
+            int r2 = gc_launch_trk_expand(ps, ctx->dchan, ctx->dplan2[s], ctx->dunit2[s], ctx->dnsamp2[s], ctx->nch, nepoch,
+                                          ctx->drounds2[s], ctx->nseg, ctx->max_n);
+            if (r2) return r2;
+        }
+        if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[s], ps));
+        return 0;
+    };
     const int slot = ctx->plan_slot;
     if (!(ctx->ahead_valid && ctx->ahead_nepoch == nepoch)) {
         if (ctx->ahead_valid) {        // planned for another batch length: the committed state is untouched
@@ -398,52 +423,40 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
             GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));
             GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[slot], 0));
         }
-        GcTimed t(ctx, "trk_plan", ps);
-        rc = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
-                                ctx->dplan2[slot], ctx->nch, nepoch);
+        rc = plan_into(slot);
         if (rc) return rc;
-        if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[slot], ps));
     }
     ctx->ahead_valid = false;
     ctx->state_cur ^= 1;               // the plan's output state is now the committed one
     if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
-    GcTrkPlan *dplan = ctx->dplan2[slot];
-    {
-        GcTimed t(ctx, "trk_expand");
-        rc = gc_launch_trk_expand(ctx->stream, ctx->dchan, dplan, ctx->dunit, ctx->dnsamp, ctx->nch, nepoch, ctx->drounds,
-                                  ctx->nseg, ctx->max_n);
-        if (rc) return rc;
-    }
-    if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));
-    ctx->plan_slot ^= 1;
-    // ---- look ahead: plan the next batch of the same length while this one is correlated ----
-    if (ctx->stream2 && !ctx->state_touched) {
-        const int ns = ctx->plan_slot;
-        GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[ns], 0));        // its previous contents were consumed
-        GcTimed t(ctx, "trk_plan", ps);
-        rc = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
-                                ctx->dplan2[ns], ctx->nch, nepoch);
-        if (rc) return rc;
-        GC_HIP(hipEventRecord(ctx->ev_plan[ns], ps));
-        ctx->ahead_valid = true;
-        ctx->ahead_nepoch = nepoch;
-    }
-    ctx->state_touched = false;
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
-        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit, ctx->drounds, ctx->dpartial, ctx->nch, nepoch, ctx->nseg,
-                                ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->drounds2[slot], ctx->dpartial, ctx->nch,
+                                nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }
+    if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));      // slot buffers consumed
+    ctx->plan_slot ^= 1;
+    // ---- look ahead: plan the next batch of the same length while this one is correlated ----
+    if (ctx->stream2 && !ctx->state_touched) {
+        const int ns = ctx->plan_slot;
+        GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[ns], 0));        // its previous contents were consumed
+        rc = plan_into(ns);
+        if (rc) return rc;
+        ctx->ahead_valid = true;
+        ctx->ahead_nepoch = nepoch;
+    }
+    ctx->state_touched = false;
     {
         GcTimed t(ctx, "trk_finish");
         rc = gc_launch_trk_finish(ctx->stream, ctx->dpartial, ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ,
-                                  ctx->nch, nepoch, ctx->nseg, ctx->ntap);
+                                  ctx->dfinish, ctx->nch, nepoch, ctx->nseg, ctx->ntap);
         if (rc) return rc;
     }
+    ctx->last_slot = slot;
     ctx->last_nepoch = nepoch;
     return GNSSCORR_OK;
 }
@@ -459,7 +472,7 @@ extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQ
     if (trkQQ)
         GC_HIP(hipMemcpyAsync(trkQQ, ctx->dcorrI, sizeof(double) * units * ctx->ntap, hipMemcpyDeviceToHost, ctx->stream));
     if (nsamp_out)
-        GC_HIP(hipMemcpyAsync(nsamp_out, ctx->dnsamp, sizeof(int) * units, hipMemcpyDeviceToHost, ctx->stream));
+        GC_HIP(hipMemcpyAsync(nsamp_out, ctx->dnsamp2[ctx->last_slot], sizeof(int) * units, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     return GNSSCORR_OK;
 }

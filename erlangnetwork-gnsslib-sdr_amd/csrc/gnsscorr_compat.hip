@@ -25,6 +25,7 @@ struct GcOnce {
     double *out = nullptr;                           // 4*GNSSCORR_MAXTAPS: corrI, corrQ, sumI, sumQ
     int *partial = nullptr;  int partial_cap = 0;    // nseg*2*ntap
     GcRound *rounds = nullptr;  int rounds_cap = 0;  // nseg*GC_MAXR
+    unsigned long long *finish = nullptr;            // GC_FINISH_SCRATCH words, zero between launches
 };
 static GcOnce g_once;
 
@@ -37,6 +38,8 @@ static int once_init(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&g_once.plan, sizeof(GcTrkPlan)));
     GC_HIP(hipMalloc((void **)&g_once.unit, sizeof(GcTrkUnit)));
     GC_HIP(hipMalloc((void **)&g_once.out, sizeof(double) * 4 * GNSSCORR_MAXTAPS));
+    GC_HIP(hipMalloc((void **)&g_once.finish, sizeof(unsigned long long) * GC_FINISH_SCRATCH));
+    GC_HIP(hipMemsetAsync(g_once.finish, 0, sizeof(unsigned long long) * GC_FINISH_SCRATCH, ctx->stream));
     return 0;
 }
 
@@ -105,7 +108,7 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
                             c.ntap, n, c.smax);
     if (rc) return rc;
     rc = gc_launch_trk_finish(ctx->stream, g_once.partial, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
-                              g_once.out + 2 * GNSSCORR_MAXTAPS, g_once.out + 3 * GNSSCORR_MAXTAPS, 1, 1, nseg,
+                              g_once.out + 2 * GNSSCORR_MAXTAPS, g_once.out + 3 * GNSSCORR_MAXTAPS, g_once.finish, 1, 1, nseg,
                               c.ntap);
     if (rc) return rc;
     double host[2 * GNSSCORR_MAXTAPS];

@@ -59,11 +59,14 @@ struct gnsscorr_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_plan[2] = {nullptr, nullptr};    // plan of slot s finished
     hipEvent_t ev_used[2] = {nullptr, nullptr};    // expand consumed slot s
-    GcTrkUnit *dunit = nullptr;
-    GcRound *drounds = nullptr;    // [unit][nseg][GC_MAXR]
+    // per-unit constants, one set per plan slot: the planner stream expands batch k+1 while batch k is correlated
+    GcTrkUnit *dunit2[2] = {nullptr, nullptr};
+    GcRound *drounds2[2] = {nullptr, nullptr};     // [unit][nseg][GC_MAXR]
+    int *dnsamp2[2] = {nullptr, nullptr};
+    int last_slot = 0;                             // slot of the last completed trk_run
     size_t plan_cap = 0;
     double *dcorrI = nullptr, *dcorrQ = nullptr, *dsumI = nullptr, *dsumQ = nullptr;
-    int *dnsamp = nullptr;
+    unsigned long long *dfinish = nullptr;     // batch-sum scratch of trk_finish
     int *dpartial = nullptr;       // [ch][epoch][segment][2*ntap] int32 partial sums
     int nseg = 1;
     int last_nepoch = 0;

@@ -148,6 +148,8 @@ int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *pl
                          int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n);
 int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch,
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max);
+// scratch: GC_FINISH_SCRATCH 64-bit words per channel, zero before the first launch (the kernel leaves them zero)
+#define GC_FINISH_SCRATCH (2 * GNSSCORR_MAXTAPS + 1)
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
-                         double *sumQ, int nch, int nepoch, int nseg, int ntap);
+                         double *sumQ, unsigned long long *scratch, int nch, int nepoch, int nseg, int ntap);
 int gc_trk_nseg(int dtype, int max_n);

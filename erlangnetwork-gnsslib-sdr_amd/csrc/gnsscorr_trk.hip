@@ -845,31 +845,47 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(const int *__restrict__
                                                          double *__restrict__ corrI,
                                                          double *__restrict__ corrQ,
                                                          double *__restrict__ sumI, double *__restrict__ sumQ,
+                                                         unsigned long long *__restrict__ scratch,
                                                          int nepoch, int nseg, int ntap)
 {
-    __shared__ long long acc[2 * GNSSCORR_MAXTAPS];
-    const int ch = blockIdx.x, tid = threadIdx.x;
+    // block (ch, b) serves epochs [256 b, 256 b + 256) of channel ch; the batch sums meet in
+    // scratch[ch] (zero between launches), and the block that arrives last converts and clears them
+    __shared__ unsigned long long acc[2 * GNSSCORR_MAXTAPS];
+    __shared__ int last;
+    constexpr int SS = 2 * GNSSCORR_MAXTAPS + 1;
+    const int ch = blockIdx.x, tid = threadIdx.x, e = blockIdx.y * 256 + tid;
+    unsigned long long *sc = scratch + (size_t)ch * SS;
     if (tid < 2 * ntap) acc[tid] = 0;
     __syncthreads();
-    long long loc[2 * GNSSCORR_MAXTAPS];
-    for (int t = 0; t < 2 * ntap; t++) loc[t] = 0;
-    for (int e = tid; e < nepoch; e += 256) {
-        const int *pp = partial + ((size_t)ch * nepoch + e) * nseg * 2 * ntap;
-        for (int t = 0; t < 2 * ntap; t++) {
-            int s = 0;
+    const int *pp = partial + ((size_t)ch * nepoch + (e < nepoch ? e : 0)) * nseg * 2 * ntap;
+    for (int t = 0; t < 2 * ntap; t++) {
+        int s = 0;
+        if (e < nepoch) {
             for (int g = 0; g < nseg; g++) s += pp[g * 2 * ntap + t];
             const double v = (double)s * (1.0 / 32.0);
             if (t < ntap) corrI[((size_t)ch * nepoch + e) * ntap + t] = v;
             else corrQ[((size_t)ch * nepoch + e) * ntap + (t - ntap)] = v;
-            loc[t] += s;
         }
+        // wavefront sum in two 16-bit halves (64 terms of either fit an int), then one LDS atomic per wave
+        const int hi = wave_sum63(s >> 16), lo = wave_sum63(s & 0xFFFF);
+        if ((tid & 63) == 63) atomicAdd(&acc[t], (unsigned long long)(((long long)hi << 16) + (long long)lo));
     }
-    for (int t = 0; t < 2 * ntap; t++) atomicAdd((unsigned long long *)&acc[t], (unsigned long long)loc[t]);
     __syncthreads();
-    if (tid < ntap) {
-        sumI[ch * ntap + tid] = (double)acc[tid] * (1.0 / 32.0);
-        sumQ[ch * ntap + tid] = (double)acc[ntap + tid] * (1.0 / 32.0);
+    if (tid < 2 * ntap) __hip_atomic_fetch_add(&sc[tid], acc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long arrived = __hip_atomic_fetch_add(&sc[SS - 1], 1ULL, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = arrived == (unsigned long long)gridDim.y - 1;
     }
+    __syncthreads();
+    if (!last) return;
+    if (tid < 2 * ntap) {
+        const long long tot = (long long)__hip_atomic_exchange(&sc[tid], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < ntap) sumI[ch * ntap + tid] = (double)tot * (1.0 / 32.0);
+        else sumQ[ch * ntap + (tid - ntap)] = (double)tot * (1.0 / 32.0);
+    }
+    if (tid == 0) __hip_atomic_store(&sc[SS - 1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8); 0 = not yet chosen
@@ -1003,10 +1019,10 @@ int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit
 }
 
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
-                         double *sumQ, int nch, int nepoch, int nseg, int ntap)
+                         double *sumQ, unsigned long long *scratch, int nch, int nepoch, int nseg, int ntap)
 {
-    hipLaunchKernelGGL(trk_finish_kernel, dim3(nch), dim3(256), 0, st, partial, corrI, corrQ, sumI, sumQ, nepoch,
-                       nseg, ntap);
+    hipLaunchKernelGGL(trk_finish_kernel, dim3(nch, (nepoch + 255) / 256), dim3(256), 0, st, partial, corrI, corrQ,
+                       sumI, sumQ, scratch, nepoch, nseg, ntap);
     GC_HIP(hipGetLastError());
     return 0;
 }
