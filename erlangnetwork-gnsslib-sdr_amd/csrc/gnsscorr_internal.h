@@ -139,7 +139,7 @@ int gc_fail(int code, const char *fmt, ...);
 // One round of the prefix-sum correlator (gnsscorr_trk.hip): the chip edges [q0, q1) its samples can
 // touch, in the numbering period * nedge + list index, and the value of its last chip.
 #define GC_MAXR 16
-struct GcRound { int q0, q1, clast, pad; };
+struct GcRound { int q0, q1, clast, w0; };     // w0: whole code periods in front of edge q0
 
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,

@@ -147,7 +147,7 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
             ro.q0 = wa * c.nedge + (int)rank[ma];
             ro.q1 = wb * c.nedge + (int)rank[mb];
             ro.clast = (int)c.code[mb];
-            ro.pad = 0;
+            ro.w0 = wa;
             rounds[((size_t)i * nseg + seg) * GC_MAXR + r] = ro;
         }
     }
@@ -515,14 +515,14 @@ struct PsLayout {
     static constexpr int LSP = NIT * SPG;                       // samples per lane and round
     static constexpr int RGRP = 256 * NIT;                      // groups per round
     static constexpr int RSAMP = 256 * LSP;                     // samples per round
-    static constexpr int RS = 256 + 1;                          // + closing column (P = total there)
+    static constexpr int LPAD = LSP + 1;                        // image stride per lane: odd in 8-byte units
     static constexpr int MAXR = GC_MAXR;                        // rounds per workgroup, at most
     static constexpr int LUTPOS = DTYPE == 2 ? 2 : 4;
     static constexpr int LUT_BYTES = 32 * 8 * LUTPOS;
     static constexpr int WT_OFF = LUT_BYTES;                    // wpre[2][8] int2 (two rounds in flight)
     static constexpr int LB_OFF = WT_OFF + 128;
-    static constexpr int LOC_OFF = LB_OFF + ((RS * 8 + 15) & ~15);
-    static constexpr int RED_OFF = LOC_OFF + ((LSP * RS * 8 + 15) & ~15);
+    static constexpr int LOC_OFF = LB_OFF + ((257 * 8 + 15) & ~15);
+    static constexpr int RED_OFF = LOC_OFF + (((256 * LPAD + 1) * 8 + 15) & ~15);
     static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
 };
 
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     using L = PsLayout<DTYPE, NIT>;
     // static, so that every LDS address is a compile-time offset
     __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
-    constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, RS = L::RS;
+    constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, LPAD = L::LPAD;
     const int tid = threadIdx.x;
     const int per_epoch = nch * nseg;
     const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     uint2 *lut = reinterpret_cast<uint2 *>(smem);
     int *wpre = reinterpret_cast<int *>(smem + L::WT_OFF);            // [2][8][2]: sums of the waves in front
     int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF);         // [256 + 1]
-    int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [LSP][RS]
+    int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [256 lanes][LPAD] + closing entry
     int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x 2*NTAP
 
     const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
@@ -644,9 +644,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
         }
         lut[tid] = v;
     }
-    // constant parts of the prefix image: row 0 and the closing column
-    for (int x = tid; x < RS; x += 256) loc[x] = make_int2(0, 0);
-    if (tid < LSP) loc[tid * RS + 256] = make_int2(0, 0);
+    // constant part of the prefix image: entry 0 of every lane (nothing summed yet) and of the closing lane
+    loc[tid * LPAD] = make_int2(0, 0);
+    if (tid == 0) loc[256 * LPAD] = make_int2(0, 0);
     for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
     if (tid < 32) wpre[tid] = 0;
     __syncthreads();
@@ -669,16 +669,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     const GcRound *myrounds = rounds + (((size_t)ch * nepoch + e) * nseg + seg) * GC_MAXR;
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
     auto edge_js = [&](int ed, int w) -> int {          // start sample of the chip the list entry names
+        // B = min{j : T(j) >= m}.  The estimate ceil((m - cs) / ci) is within one sample of it (its
+        // error is ~1e-11 samples for j < 2^15), so B is one of jc-1, jc, jc+1: T decides which.
         const int m = (int)(short)(ed & 0xFFFF) + w * clen;
-        int js = (int)ceil(((double)m - cs) * inv);
-        if (js < 1) js = 1;
-        for (int it = 0; it < 8 && js > 1 && chipT(js - 1) >= m; it++) js--;
-        for (int it = 0; it < 8 && chipT(js) < m; it++) js++;
-        return js;
+        int jc = (int)ceil(((double)m - cs) * inv);
+        if (jc < 1) jc = 1;
+        const bool below = chipT(jc - 1) >= m, at = chipT(jc) >= m;
+        return below ? jc - 1 : (at ? jc : jc + 1);
     };
-    auto edge_load = [&](int q, int *w) -> int {
-        *w = 0;
-        while (q >= nedge) { q -= nedge; ++*w; }
+    auto edge_load = [&](int q, int w0, int *w) -> int {  // w0: code periods in front of the round's first edge
+        q -= w0 * nedge;
+        while (q >= nedge) { q -= nedge; ++w0; }
+        *w = w0;
         return edges[q];
     };
 
@@ -686,10 +688,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
         if (r == 1) GC_STAMP(2);
         if (r + 1 < nround) load_round(r + 1, vnext);
         const GcRound ro = myrounds[r];
-        const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast;
+        const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0;
         int q = rq0 + tid, ew = 0, ed = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
-        if (q < q1) ed = edge_load(q, &ew);            // in flight during the mixing phase
+        if (q < q1) ed = edge_load(q, rw0, &ew);       // in flight during the mixing phase
         busy = busy || (rq0 + wv * 64 < q1);
         const int kl = klo + r * RSAMP;
 
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                     aI = __builtin_amdgcn_sdot4((int)wd, (int)l.x, aI, false);
                     aQ = __builtin_amdgcn_sdot4((int)wd, (int)l.y, aQ, false);
                     const int p = it * SPG + i + 1;
-                    if (p < LSP) loc[p * RS + tid] = make_int2(aI, aQ);
+                    if (p < LSP) loc[tid * LPAD + p] = make_int2(aI, aQ);
                     phi += ps;
                 }
             }
@@ -783,8 +785,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                 for (int t = 0; t < NTAP; t++) {
                     int ee = js - toff[t];
                     ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
-                    const int col = ee / LSP, row = ee % LSP;
-                    const int2 a = loc[row * RS + col], b = lbase[col];
+                    const int col = ee / LSP;             // the lane that owns sample ee; its image entry is ee + col
+                    const int2 a = loc[ee + col], b = lbase[col];
                     const unsigned pI = (unsigned)(a.x + b.x), pQ = (unsigned)(a.y + b.y);
                     if (PM1) {
                         accI[t] += (pI ^ sg) - sg;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                     }
                 }
                 q += 256;
-                if (q < q1) { ed = edge_load(q, &ew); js = edge_js(ed, ew) - roff; }
+                if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(ed, ew) - roff; }
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
