@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     }
     // constant part of the prefix image: entry 0 of every lane (nothing summed yet) and of the closing lane
     loc[tid * LPAD] = make_int2(0, 0);
-    if (tid == 0) loc[256 * LPAD] = make_int2(0, 0);
+    if (tid == 0) { loc[256 * LPAD] = make_int2(0, 0); lbase[256] = make_int2(0, 0); }   // there P = slot 4 = total
     for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
     if (tid < 32) wpre[tid] = 0;
     __syncthreads();
@@ -757,20 +757,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                 atomicAdd(&wp[2 * slot + 1], tQ);
             }
         }
+        lbase[tid] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
         if (r == 1) GC_STAMP(3);
         __syncthreads();
         if (r == 1) GC_STAMP(4);
-        {   // sums in front of this lane's span: lanes of this wave, then the waves in front
-            const int2 pre = *reinterpret_cast<const int2 *>(&wp[2 * wv]);
+        {
             const int2 tv = *reinterpret_cast<const int2 *>(&wp[8]);
-            lbase[tid] = make_int2(sI - aI + pre.x, sQ - aQ + pre.y);
-            if (tid == 0) lbase[256] = tv;
             const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
             finI += (unsigned)rlast * (unsigned)ti;         // c_b P(S), the term of the round's last chip
             finQ += (unsigned)rlast * (unsigned)tq;
             if (tid < 16) wpre[((r + 1) & 1) * 16 + tid] = 0;   // the other copy, for the next round
         }
-        __syncthreads();
         if (r == 1) GC_STAMP(5);
 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
@@ -786,8 +783,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                     int ee = js - toff[t];
                     ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
                     const int col = ee / LSP;             // the lane that owns sample ee; its image entry is ee + col
+                    // running sum inside the lane + lanes in front inside the wave + waves in front
                     const int2 a = loc[ee + col], b = lbase[col];
-                    const unsigned pI = (unsigned)(a.x + b.x), pQ = (unsigned)(a.y + b.y);
+                    const int2 w = *reinterpret_cast<const int2 *>(&wp[2 * (col >> 6)]);
+                    const unsigned pI = (unsigned)(a.x + b.x + w.x), pQ = (unsigned)(a.y + b.y + w.y);
                     if (PM1) {
                         accI[t] += (pI ^ sg) - sg;
                         accQ[t] += (pQ ^ sg) - sg;
