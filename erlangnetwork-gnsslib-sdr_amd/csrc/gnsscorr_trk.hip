@@ -127,7 +127,7 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel): round r of workgroup
     // seg covers samples [kl, kl + rsamp) of the period and can touch the chips T(first sample) ..
     // T(last sample + 2 smax); rank[] turns those into positions in the code's edge list
-    if (!rounds || !(p.n > 0 && p.n <= max_n && u.ci > 0.0 && u.ci <= 4.0)) return;
+    if (!rounds || !(p.n > 0 && p.n <= max_n && u.ci > 0.0 && u.ci < (double)c.clen)) return;
     const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
     const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
     const unsigned short *rank = (const unsigned short *)(c.code + 1024);
@@ -141,8 +141,8 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
             const int kend = (kl + rsamp < p.n ? kl + rsamp : p.n);
             int ma = (int)__fma_rn((double)kfirst, u.ci, u.cs);
             int mb = (int)__fma_rn((double)(kend - 1 + 2 * c.smax), u.ci, u.cs), wa = 0, wb = 0;
-            while (ma >= c.clen) { ma -= c.clen; ++wa; }
-            while (mb >= c.clen) { mb -= c.clen; ++wb; }
+            wa = ma / c.clen; ma -= wa * c.clen;
+            wb = mb / c.clen; mb -= wb * c.clen;
             GcRound ro;
             ro.q0 = wa * c.nedge + (int)rank[ma];
             ro.q1 = wb * c.nedge + (int)rank[mb];
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     int *pout = partial + (((size_t)ch * nepoch + e) * nseg + seg) * 2 * ntap_stride;
     const int g0 = seg * RGRP * rpw;
     const double ci = u.ci, cs = u.cs, inv = u.inv_ci;
-    // outside the reference's (nsamp+100) scratch, nothing left for this workgroup, or a code NCO
-    // this form does not serve (more than 4 chips per sample)
-    if (n <= 0 || n > max_n || g0 >= G || !(ci > 0.0 && ci <= 4.0)) {
+    // outside the reference's (nsamp+100) scratch, nothing left for this workgroup, or a chip step
+    // for which the reference's one-subtraction code wrap (src/sdrcmn.c:617) is undefined
+    if (n <= 0 || n > max_n || g0 >= G || !(ci > 0.0 && ci < (double)clen)) {
         if (tid < 2 * ntap_stride) pout[tid] = 0;
         return;
     }
@@ -679,7 +679,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     };
     auto edge_load = [&](int q, int w0, int *w) -> int {  // w0: code periods in front of the round's first edge
         q -= w0 * nedge;
-        while (q >= nedge) { q -= nedge; ++w0; }
+        if (q >= nedge) {                                 // a round seldom spans a code period
+            const int wq = q / nedge;
+            q -= wq * nedge;
+            w0 += wq;
+        }
         *w = w0;
         return edges[q];
     };

@@ -169,3 +169,83 @@ def test_consecutive_batches_and_lookahead_planner(gc, orc, engine):
     II2, QQ2, _ = engine.trk_fetch()
     oII2, oQQ2, _, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 3, mode=1)
     assert np.array_equal(II2, oII2) and np.array_equal(QQ2, oQQ2)
+
+
+def _code_case(case, rng):
+    """(code, crate, coff, n): code shapes that take the correlator's different paths."""
+    if case == "multilevel":        # steps other than +-2 between chips: the multiplying look-up loop
+        return rng.integers(-3, 4, size=1023).astype(np.int16), 1.023e6 + 2.0, 511.75, 16368
+    if case == "constant":          # no chip edge at all
+        return np.ones(1023, np.int16), 1.023e6, 17.5, 16368
+    if case == "sparse":            # a handful of edges: most lanes of the look-up phase idle
+        c = np.ones(1023, np.int16)
+        c[[5, 6, 400, 1022]] = -1
+        return c, 1.023e6 - 1.0, 1000.9, 16370
+    if case == "short_fast":        # 2.5 chips per sample over a 10-chip code: hundreds of periods per round
+        return rng.choice(np.array([-1, 1], np.int16), size=10), 2.5 * F_SF, 3.3, 9000
+    if case == "slow":              # 200 samples per chip
+        return rng.choice(np.array([-1, 1], np.int16), size=1023), F_SF / 200.0, 77.2531, 16368
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("case", ["multilevel", "constant", "sparse", "short_fast", "slow"])
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_correlator_symbol_code_shapes(gc, orc, case, dtype):
+    """correlator() on codes and chip rates beyond GPS L1CA: multi-level chips, no / few chip edges, many
+    chips per sample and many samples per chip (ref src/sdrcmn.c:608-621 wraps any code of length len
+    as long as the chip step stays below len)."""
+    L = gc.lib()
+    rng = np.random.default_rng({"multilevel": 1, "constant": 2, "sparse": 3, "short_fast": 4, "slow": 5}[case] * 10 + dtype)
+    code, crate, coff, n = _code_case(case, rng)
+    data = rng.integers(-128, 128, size=n * dtype, dtype=np.int8)
+    s = np.array([2, 5], np.int32)
+    II, QQ = np.zeros(5), np.zeros(5)
+    remc, remp = C.c_double(), C.c_double()
+    freq = 4.092e6 + 777.0 if dtype == 1 else -2345.6
+    L.correlator(data.ctypes.data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s.ctypes.data, 2,
+                 II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code.ctypes.data, len(code))
+    oII, oQQ, orc_c, orc_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s, code, 1)
+    assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+    assert remc.value == orc_c and remp.value == orc_p
+    if case != "short_fast":        # the literal NCO's running fp64 sum drifts over 22500 chips
+        sII, sQQ, _, _ = orc.correlator(data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s, code, 0)
+        assert rel_err(II, sII) <= 1e-4 and rel_err(QQ, sQQ) <= 1e-4
+
+
+def test_prefix_and_replica_forms_agree(gc, orc, engine, tmp_path):
+    """The two independent HIP implementations of the correlator -- prefix sums over chip edges (default)
+    and the sample-by-sample replica form (GNSSCORR_TRK_ALGO=replica) -- must agree bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    nsamples = 16 * 8192
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[2, 11, 30], nsamples=nsamples,
+                                       seed=404, buffloc0=123)
+    engine.trk_run(5)
+    II, QQ, ns = engine.trk_fetch()
+    script = tmp_path / "replica.py"
+    script.write_text(f"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+import gnsscorr_loader
+gc = gnsscorr_loader.load()
+rng = np.random.default_rng(404)
+data = rng.integers(-60, 61, size=({nsamples}, 2), dtype=np.int8)
+data.reshape(-1)[:4] = [-128, 127, -128, 127]
+eng = gc.Engine(0)
+eng.ring_create(1, 2, {nsamples})
+eng.ring_push_raw(1, data, {nsamples})
+eng.set_channels([gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in (2, 11, 30)])
+eng.trk_set_state(json.loads({repr(json.dumps(states))}))
+eng.trk_run(5)
+II, QQ, ns = eng.trk_fetch()
+print(json.dumps(dict(II=II.tolist(), QQ=QQ.tolist(), ns=ns.tolist())))
+""")
+    env = dict(os.environ, GNSSCORR_TRK_ALGO="replica")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert np.array_equal(np.array(r["ns"]), ns)
+    assert np.array_equal(np.array(r["II"]), II) and np.array_equal(np.array(r["QQ"]), QQ)
