@@ -43,6 +43,25 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a kernel, from the committed rocprofv3 PMC passes of this same
+    workload (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof.sh; profiles/README.md).
+    gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE tallies wide reads at half their bytes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "*_pmc_fetch_write.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        f = [v for k, v in d["FETCH_SIZE_KB_per_dispatch"].items() if k.startswith(kernel_prefix)]
+        w = [v for k, v in d["WRITE_SIZE_KB_per_dispatch"].items() if k.startswith(kernel_prefix)]
+        if not f or not w:
+            return None, None
+        return (2.0 * f[0] + w[0]) * 1024.0, os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    except Exception:
+        return None, None
+
+
 def make_signal(gc, synth, nms, seed):
     """nms milliseconds of int8 IQ with ~10 of PRN 1..32 present; cached in /tmp."""
     cache = f"/tmp/gnsscorr_if_{nms}ms_{seed}.npy"
@@ -257,8 +276,9 @@ def main():
     bytes_unit = 32840                                    # algorithmic bytes per channel-epoch (int8 IQ, 5 taps)
     k_avg_ms = k_ms / max(k_n, 1)
     ach = NCH * E * bytes_unit / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
+    t_bytes, t_src = pmc_traffic("trk_corr")
     roof = dict(kernel="trk_corr", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=ach / HBM_PEAK_GBS, traffic=None, launch_ms=k_avg_ms, launches=k_n,
+                frac=ach / HBM_PEAK_GBS, traffic=t_bytes, traffic_source=t_src, launch_ms=k_avg_ms, launches=k_n,
                 algorithmic_bytes_per_launch=NCH * E * bytes_unit)
     out = {
         "metric": METRIC, "value": value, "unit": "correlations/s", "n_gpus": world, "steps": args.steps,
@@ -311,7 +331,7 @@ def main():
             "acquired": [c.prn for c, r in zip(chans, res) if r["flagacq"]],
             "kernels_ms_per_search": {"acq_fwd": f_ms / max(f_n, 1), "acq_corr": c_avg},
             "roofline": dict(kernel="acq_corr", bound="hbm", achieved=a_ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=a_ach / HBM_PEAK_GBS, traffic=None, launch_ms=c_avg, launches=c_n,
+                             frac=a_ach / HBM_PEAK_GBS, traffic=pmc_traffic("acq_corr")[0], launch_ms=c_avg, launches=c_n,
                              algorithmic_bytes_per_launch=computed * abytes),
         }
 
