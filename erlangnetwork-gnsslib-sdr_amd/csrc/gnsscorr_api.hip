@@ -54,9 +54,12 @@ extern "C" int gnsscorr_create(gnsscorr_ctx **out, int device, void *stream)
         ctx->own_stream = true;
     }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    if (!ctx->stream2 || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) ctx->stream3 = nullptr;
     for (int i = 0; i < 2 && ctx->stream2; i++) {
         hipEventCreateWithFlags(&ctx->ev_plan[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&ctx->ev_used[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ctx->ev_corr[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ctx->ev_fin[i], hipEventDisableTiming);
     }
     *out = ctx;
     return GNSSCORR_OK;
@@ -82,7 +85,8 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     hipFree(ctx->dsumI);  ctx->dsumI = nullptr;
     hipFree(ctx->dfinish); ctx->dfinish = nullptr;
     hipFree(ctx->dsumQ);  ctx->dsumQ = nullptr;
-    hipFree(ctx->dpartial); ctx->dpartial = nullptr;
+    for (int i = 0; i < 2; i++) { hipFree(ctx->dpartial2[i]); ctx->dpartial2[i] = nullptr; }
+    ctx->fin_pending[0] = ctx->fin_pending[1] = false;
     for (int i = 0; i < 2; i++) {
         hipFree(ctx->dunit2[i]); ctx->dunit2[i] = nullptr;
         hipFree(ctx->drounds2[i]); ctx->drounds2[i] = nullptr;
@@ -97,6 +101,7 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
     gc_acq_free(ctx);
     free_trk_buffers(ctx);
     free_channels(ctx);
@@ -107,18 +112,32 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_plan[i]) hipEventDestroy(ctx->ev_plan[i]);
         if (ctx->ev_used[i]) hipEventDestroy(ctx->ev_used[i]);
+        if (ctx->ev_corr[i]) hipEventDestroy(ctx->ev_corr[i]);
+        if (ctx->ev_fin[i]) hipEventDestroy(ctx->ev_fin[i]);
     }
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) hipStreamDestroy(ctx->stream3);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 extern "C" void *gnsscorr_stream(gnsscorr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// Makes the main stream wait for the tracking outputs of the last batch (its finish runs on a stream
+// of its own).
+static int outputs_ready(gnsscorr_ctx *ctx)
+{
+    if (ctx->fin_pending[ctx->last_slot])
+        GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[ctx->last_slot], 0));
+    return GNSSCORR_OK;
+}
+
 extern "C" int gnsscorr_sync(gnsscorr_ctx *ctx)
 {
     if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
     GC_HIP(hipSetDevice(ctx->device));
+    int rc = outputs_ready(ctx);
+    if (rc) return rc;
     GC_HIP(hipStreamSynchronize(ctx->stream));
     return GNSSCORR_OK;
 }
@@ -332,6 +351,7 @@ extern "C" int gnsscorr_trk_set_state(gnsscorr_ctx *ctx, int ch0, int nch, const
     static_assert(sizeof(gnsscorr_trkstate_t) == sizeof(GcTrkState), "state layout");
     GC_HIP(hipSetDevice(ctx->device));
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ahead_valid = false;                                         // ... and is dropped
     ctx->state_touched = true;
@@ -347,6 +367,7 @@ extern "C" int gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch, gnssc
         return gc_fail(GNSSCORR_EINVAL, "trk_get_state: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
     GC_HIP(hipSetDevice(ctx->device));
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     GC_HIP(hipMemcpyAsync(st, ctx->dstate2[ctx->state_cur] + ch0, sizeof(GcTrkState) * nch, hipMemcpyDeviceToHost,
                           ctx->stream));
@@ -359,6 +380,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     const size_t units = (size_t)ctx->nch * nepoch;
     if (units <= ctx->plan_cap) return GNSSCORR_OK;
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->ahead_valid) {            // a look-ahead plan advanced the state one batch: roll it back
         ctx->ahead_valid = false;
@@ -376,7 +398,8 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
         const int s = gc_trk_nseg(ctx->hchan[i].dtype, ctx->max_n);
         if (s > ctx->nseg) ctx->nseg = s;
     }
-    GC_HIP(hipMalloc((void **)&ctx->dpartial, sizeof(int) * units * ctx->nseg * 2 * ctx->ntap));
+    for (int i = 0; i < 2; i++)
+        GC_HIP(hipMalloc((void **)&ctx->dpartial2[i], sizeof(int) * units * ctx->nseg * 2 * ctx->ntap));
     for (int i = 0; i < 2; i++) {
         GC_HIP(hipMalloc((void **)&ctx->dunit2[i], sizeof(GcTrkUnit) * units));
         GC_HIP(hipMalloc((void **)&ctx->dnsamp2[i], sizeof(int) * units));
@@ -431,14 +454,19 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
+    // the slot's partial sums were last read by the finish of two batches ago (planner stream)
+    if (ctx->fin_pending[slot]) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[slot], 0));
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
-        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->drounds2[slot], ctx->dpartial, ctx->nch,
-                                nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->drounds2[slot], ctx->dpartial2[slot],
+                                ctx->nch, nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }
-    if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));      // slot buffers consumed
+    if (ctx->stream2) {
+        GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));                    // slot buffers consumed
+        GC_HIP(hipEventRecord(ctx->ev_corr[slot], ctx->stream));
+    }
     ctx->plan_slot ^= 1;
     // ---- look ahead: plan the next batch of the same length while this one is correlated ----
     if (ctx->stream2 && !ctx->state_touched) {
@@ -450,11 +478,19 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         ctx->ahead_nepoch = nepoch;
     }
     ctx->state_touched = false;
+    // ---- finish on its own stream: the main stream goes straight from this batch's correlator to the
+    // next one's, the outputs become valid at ev_fin[slot] ----
     {
-        GcTimed t(ctx, "trk_finish");
-        rc = gc_launch_trk_finish(ctx->stream, ctx->dpartial, ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ,
+        hipStream_t fs = ctx->stream3 ? ctx->stream3 : ctx->stream;
+        if (ctx->stream3) GC_HIP(hipStreamWaitEvent(fs, ctx->ev_corr[slot], 0));
+        GcTimed t(ctx, "trk_finish", fs);
+        rc = gc_launch_trk_finish(fs, ctx->dpartial2[slot], ctx->dcorrI, ctx->dcorrQ, ctx->dsumI, ctx->dsumQ,
                                   ctx->dfinish, ctx->nch, nepoch, ctx->nseg, ctx->ntap);
         if (rc) return rc;
+        if (ctx->stream3) {
+            GC_HIP(hipEventRecord(ctx->ev_fin[slot], fs));
+            ctx->fin_pending[slot] = true;
+        }
     }
     ctx->last_slot = slot;
     ctx->last_nepoch = nepoch;
@@ -466,6 +502,7 @@ extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQ
 {
     if (!ctx || !ctx->last_nepoch) return gc_fail(GNSSCORR_ESTATE, "trk_fetch: no completed trk_run");
     GC_HIP(hipSetDevice(ctx->device));
+    { int rc = outputs_ready(ctx); if (rc) return rc; }
     const size_t units = (size_t)ctx->nch * ctx->last_nepoch;
     if (trkII)
         GC_HIP(hipMemcpyAsync(trkII, ctx->dcorrQ, sizeof(double) * units * ctx->ntap, hipMemcpyDeviceToHost, ctx->stream));
@@ -481,6 +518,7 @@ extern "C" int gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *
 {
     if (!ctx || !ctx->last_nepoch) return gc_fail(GNSSCORR_ESTATE, "trk_fetch_sums: no completed trk_run");
     GC_HIP(hipSetDevice(ctx->device));
+    { int rc = outputs_ready(ctx); if (rc) return rc; }
     const size_t n = (size_t)ctx->nch * ctx->ntap;
     if (sumI) GC_HIP(hipMemcpyAsync(sumI, ctx->dsumQ, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
     if (sumQ) GC_HIP(hipMemcpyAsync(sumQ, ctx->dsumI, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -491,6 +529,7 @@ extern "C" int gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *
 extern "C" int gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ)
 {
     if (!ctx || !ctx->dcorrI) return gc_fail(GNSSCORR_ESTATE, "trk_devptrs: no trk_run yet");
+    { int rc = outputs_ready(ctx); if (rc) return rc; }     // work queued on the context stream after this sees them
     if (trkII) *trkII = ctx->dcorrQ;
     if (trkQQ) *trkQQ = ctx->dcorrI;
     return GNSSCORR_OK;

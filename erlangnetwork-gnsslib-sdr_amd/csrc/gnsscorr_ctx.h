@@ -56,7 +56,8 @@ struct gnsscorr_ctx {
     bool ahead_valid = false;                      // dplan2[plan_slot] already planned (look-ahead)
     int ahead_nepoch = 0;
     bool state_touched = true;                     // set_state since the last run: do not look ahead
-    hipStream_t stream2 = nullptr;
+    hipStream_t stream2 = nullptr;                 // planner stream
+    hipStream_t stream3 = nullptr;                 // finish stream
     hipEvent_t ev_plan[2] = {nullptr, nullptr};    // plan of slot s finished
     hipEvent_t ev_used[2] = {nullptr, nullptr};    // expand consumed slot s
     // per-unit constants, one set per plan slot: the planner stream expands batch k+1 while batch k is correlated
@@ -67,7 +68,10 @@ struct gnsscorr_ctx {
     size_t plan_cap = 0;
     double *dcorrI = nullptr, *dcorrQ = nullptr, *dsumI = nullptr, *dsumQ = nullptr;
     unsigned long long *dfinish = nullptr;     // batch-sum scratch of trk_finish
-    int *dpartial = nullptr;       // [ch][epoch][segment][2*ntap] int32 partial sums
+    int *dpartial2[2] = {nullptr, nullptr};    // per slot: [ch][epoch][segment][2*ntap] int32 partial sums
+    hipEvent_t ev_corr[2] = {nullptr, nullptr};   // correlator of slot s finished (main stream)
+    hipEvent_t ev_fin[2] = {nullptr, nullptr};    // finish of slot s done (finish stream): outputs valid
+    bool fin_pending[2] = {false, false};         // ev_fin[s] has been recorded
     int nseg = 1;
     int last_nepoch = 0;
 

@@ -249,3 +249,27 @@ print(json.dumps(dict(II=II.tolist(), QQ=QQ.tolist(), ns=ns.tolist())))
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert np.array_equal(np.array(r["ns"]), ns)
     assert np.array_equal(np.array(r["II"]), II) and np.array_equal(np.array(r["QQ"]), QQ)
+
+
+def test_planner_chain_long_batch(gc, orc, engine):
+    """400 code periods per channel in one batch: the planner's chained closed forms (code / carrier
+    remainders, currnsamp) must track the oracle's to the last bit over the whole chain -- any one-ulp
+    slip in a remainder would show up in the samples-per-period sequence or the final state."""
+    nepoch = 400
+    nsamples = 16368 * (nepoch + 12)
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[1, 6, 14, 23, 31, 9, 18, 27],
+                                       nsamples=nsamples, seed=909, buffloc0=3)
+    # spread the frequencies: negative and large carrier offsets, code rates off nominal by up to 8 Hz
+    rng = np.random.default_rng(910)
+    for i, s in enumerate(states):
+        s["carrfreq"] = float(rng.uniform(-9000, 9000)) * (-1 if i % 2 else 1)
+        s["codefreq"] = chans[i].crate + float(rng.uniform(-8, 8))
+    engine.trk_set_state(states)
+    engine.trk_run(nepoch)
+    II, QQ, ns = engine.trk_fetch()
+    fin = engine.trk_get_state()
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=1)
+    assert np.array_equal(ns, ons)
+    for a, b in zip(fin, ofin):
+        assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
+    assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
