@@ -246,7 +246,7 @@ def main():
         pending[0].wait()
         pending[0] = None
     barrier()
-    eng.timing(True)
+    eng.timing(not os.environ.get("BENCH_NOTIMING"))      # (debug) per-kernel HIP events off
     eng.timing_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -421,6 +421,9 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     // run on the planner stream into slot buffers, ev_plan[slot] marks them ready
     hipStream_t ps = ctx->stream2 ? ctx->stream2 : ctx->stream;
     auto plan_into = [&](int s) -> int {
+        // the slot's partial sums were last read by the finish of two batches ago: ordering the plan
+        // behind it lets ev_plan[s] stand for "slot s is free and planned" on the main stream
+        if (ctx->stream2 && ctx->fin_pending[s]) GC_HIP(hipStreamWaitEvent(ps, ctx->ev_fin[s], 0));
         {
             GcTimed t(ctx, "trk_plan", ps);
             int r2 = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
@@ -454,8 +457,7 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
-    // the slot's partial sums were last read by the finish of two batches ago (planner stream)
-    if (ctx->fin_pending[slot]) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[slot], 0));
+    if (!ctx->stream2 && ctx->fin_pending[slot]) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[slot], 0));
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
@@ -463,15 +465,12 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
                                 ctx->nch, nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }
-    if (ctx->stream2) {
-        GC_HIP(hipEventRecord(ctx->ev_used[slot], ctx->stream));                    // slot buffers consumed
-        GC_HIP(hipEventRecord(ctx->ev_corr[slot], ctx->stream));
-    }
+    if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_corr[slot], ctx->stream));     // slot buffers consumed, partials ready
     ctx->plan_slot ^= 1;
     // ---- look ahead: plan the next batch of the same length while this one is correlated ----
     if (ctx->stream2 && !ctx->state_touched) {
         const int ns = ctx->plan_slot;
-        GC_HIP(hipStreamWaitEvent(ps, ctx->ev_used[ns], 0));        // its previous contents were consumed
+        GC_HIP(hipStreamWaitEvent(ps, ctx->ev_corr[ns], 0));        // its previous contents were consumed
         rc = plan_into(ns);
         if (rc) return rc;
         ctx->ahead_valid = true;
