@@ -86,7 +86,8 @@ def channel_set(gc, rank):
     """32 channels per rank: PRN 1..32 on rank 0 (bin/gnss-sdrcli.ini:5-9), the next C/A PRNs of the
     210-entry table on the other ranks (weak scaling in channels)."""
     prns = [((32 * rank + i) % 210) + 1 for i in range(NCH)]
-    return [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in prns]
+    corrn = int(os.environ.get("BENCH_CORRN", "2"))      # (side experiments: 6 = the shipped 13-tap front-end files)
+    return [gc.Channel(p, dtype=2, f_if=0.0, corrn=corrn, corrd=3, corrp=3) for p in prns]
 
 
 def cpu_baseline_tracking(orc, data, ringlen, chans, states, seconds_budget=12.0):

@@ -600,7 +600,7 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 }
 
 template <int DTYPE, int NTAP, int NIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 8 : 4, 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 21 ? 2 : 1), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
                                                           const GcTrkUnit *__restrict__ unit,
                                                           const GcRound *__restrict__ rounds,
                                                           int *__restrict__ partial, int nch, int nepoch, int nseg,
@@ -751,11 +751,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
     };
 
     auto round = [&](int r, uint4 *vdata, uint4 *vnext) {
+        // opaque copy of the lane id: per-lane address arithmetic stays inside the round instead of being
+        // hoisted out of the loop over rounds into registers that would then spill
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         if (r == 1) GC_STAMP(2);
         if (r + 1 < nround) load_round(r + 1, vnext);
         const GcRound ro = myrounds[r];
         const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0;
-        int q = rq0 + tid, ew = 0, ed = 0;
+        int q = rq0 + tl, ew = 0, ed = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
         if (q < q1) ed = edge_load(q, rw0, &ew);       // in flight during the mixing phase
         busy = busy || (rq0 + wv * 64 < q1);
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
             unsigned long long phi = phir;              // phase of the lane's first sample this round
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int gl = tid * NIT + it, g = g0 + r * RGRP + gl;
+                const int gl = tl * NIT + it, g = g0 + r * RGRP + gl;
                 uint4 v = vdata[it];
                 const int kb = kl + gl * SPG;
                 if (ragged) {
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                     aI = __builtin_amdgcn_sdot4((int)wd, (int)l.x, aI, false);
                     aQ = __builtin_amdgcn_sdot4((int)wd, (int)l.y, aQ, false);
                     const int p = it * SPG + i + 1;
-                    if (p < LSP) loc[tid * LPAD + p] = make_int2(aI, aQ);
+                    if (p < LSP) loc[tl * LPAD + p] = make_int2(aI, aQ);
                     phi += ps;
                 }
             }
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
                 atomicAdd(&wp[2 * slot + 1], tQ);
             }
         }
-        lbase[tid] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
+        lbase[tl] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
         if (r == 1) GC_STAMP(3);
         __syncthreads();
         if (r == 1) GC_STAMP(4);
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NIT == 1 ? 
             const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
             finI += (unsigned)rlast * (unsigned)ti;         // c_b P(S), the term of the round's last chip
             finQ += (unsigned)rlast * (unsigned)tq;
-            if (tid < 16) wpre[((r + 1) & 1) * 16 + tid] = 0;   // the other copy, for the next round
+            if (tl < 16) wpre[((r + 1) & 1) * 16 + tl] = 0;   // the other copy, for the next round
         }
         if (r == 1) GC_STAMP(5);
 
