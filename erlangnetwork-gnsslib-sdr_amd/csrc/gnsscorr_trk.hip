@@ -600,7 +600,7 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 }
 
 template <int DTYPE, int NTAP, int NIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 21 ? 2 : 1), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 13 ? 3 : (NTAP <= 21 ? 2 : 1)), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
                                                           const GcTrkUnit *__restrict__ unit,
                                                           const GcRound *__restrict__ rounds,
                                                           int *__restrict__ partial, int nch, int nepoch, int nseg,
@@ -850,6 +850,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
                 const unsigned sg = (unsigned)(dd >> 31);
 #pragma unroll
                 for (int t = 0; t < NTAP; t++) {
+                    // many taps: a compiler barrier every four keeps their look-ups from all being issued
+                    // (and held in registers) before the first one is consumed
+                    if (NTAP > 7 && t % 4 == 0 && t) asm volatile("" ::: "memory");
                     int ee = js - toff[t];
                     ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
                     const int col = ee / LSP;             // the lane that owns sample ee; its image entry is ee + col
@@ -861,8 +864,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
                         accI[t] += (pI ^ sg) - sg;
                         accQ[t] += (pQ ^ sg) - sg;
                     } else {
-                        accI[t] += (unsigned)dd * pI;
-                        accQ[t] += (unsigned)dd * pQ;
+                        // 32-bit products kept apart from the adds: fused into v_mad_u64_u32 they would
+                        // turn every accumulator into a 64-bit register pair
+                        unsigned mI = (unsigned)dd * pI, mQ = (unsigned)dd * pQ;
+                        asm volatile("" : "+v"(mI), "+v"(mQ));
+                        accI[t] += mI;
+                        accQ[t] += mQ;
                     }
                 }
                 q += 256;
