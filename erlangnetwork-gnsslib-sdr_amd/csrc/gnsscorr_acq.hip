@@ -42,7 +42,8 @@ using gcfft::csub;
 struct GcAcqWork {
     float2 *tw16k = nullptr;    // exp(-2 pi i t/16384), t < 16384
     float2 *tw32k = nullptr;    // exp(-2 pi i t/32768), t < 16384
-    float2 *X = nullptr;        // [grid][iter][bin][2][16384]
+    float2 *tw32p = nullptr;    // the same twiddles in pass order: exp(-2 pi i freq_of(p)/32768), p < 16384
+    float2 *X = nullptr;        // [grid][iter][bin][2][16384]: X[f] and X[f + 16384] at the pass position of f
     size_t  X_elems = 0;
     float2 *C = nullptr;        // [ch][2][16384]
     GcAcqRow *rows = nullptr;   // [ch][iter][bin]
@@ -67,7 +68,7 @@ __constant__ signed char aCos32[32] = {32, 31, 30, 27, 23, 18, 12, 6, 0, -6, -12
 __constant__ signed char aSin32[32] = {0, 6, 12, 18, 23, 27, 30, 31, 32, 31, 30, 27, 23, 18, 12, 6,
                                        0, -6, -12, -18, -23, -27, -30, -31, -32, -31, -30, -27, -23, -18, -12, -6};
 
-__global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k)
+__global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k, float2 *tw32p)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= GC_LH) return;
@@ -76,35 +77,50 @@ __global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k)
     tw16k[t] = make_float2((float)c, (float)s);
     sincospi(-2.0 * (double)t / 32768.0, &s, &c);
     tw32k[t] = make_float2((float)c, (float)s);
+    sincospi(-2.0 * (double)gcfft::freq_of(t) / 32768.0, &s, &c);
+    tw32p[t] = make_float2((float)c, (float)s);
 }
 
-// Forward 32768-point transform of a sequence given by a per-sample functor:
-// one decimation-in-frequency stage on the fly, a[j] = x[j] + x[j+16384] feeds the even
-// frequencies and b[j] = (x[j] - x[j+16384]) w^j (w = exp(-2 pi i/32768)) the odd ones, then
-// two 16384-point transforms.  out[0][p] / out[1][p] = X[2 f(p)] / X[2 f(p) + 1], p in pass order.
+// Forward 32768-point transform of a sequence given by a per-sample functor, decimated in time:
+// Ee = FFT16k(x[2j]), Oo = FFT16k(x[2j+1]), X[f] = Ee[f] + w^f Oo[f], X[f + 16384] = Ee[f] - w^f Oo[f]
+// (w = exp(-2 pi i/32768), f < 16384).  out[0][p] / out[1][p] = X[f(p)] / X[f(p) + 16384], p in pass
+// order: exactly the pairs the inverse transform of the correlation wants side by side (acq_corr).
+// Ee waits in out[0] while Oo is computed (each lane reads back what it wrote itself).
 template <class F>
 __device__ __forceinline__ void fwd32k_store(F sample, float2 *lds, const float2 *__restrict__ tw16k,
-                                             const float2 *__restrict__ tw32k, float2 *__restrict__ out,
+                                             const float2 *__restrict__ tw32p, float2 *__restrict__ out,
                                              int tid)
 {
-    auto store_to = [&](float2 *dst) {
-        return [dst](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
-            float4 *d = reinterpret_cast<float4 *>(dst + p);
-            d[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
-            d[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
-        };
-    };
-    gcfft::dif<-1>([&](int j) { return cadd(sample(j), sample(j + GC_LH)); }, store_to(out), lds, tw16k, tid);
+    gcfft::dif<-1>([&](int j) { return sample(2 * j); },
+                   [out](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                       float4 *d = reinterpret_cast<float4 *>(out + p);
+                       d[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
+                       d[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
+                   },
+                   lds, tw16k, tid);
     __syncthreads();
-    gcfft::dif<-1>([&](int j) { return cmul(csub(sample(j), sample(j + GC_LH)), tw32k[j]); },
-                   store_to(out + GC_LH), lds, tw16k, tid);
+    gcfft::dif<-1>([&](int j) { return sample(2 * j + 1); },
+                   [out, tw32p](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                       float4 *lo = reinterpret_cast<float4 *>(out + p);
+                       float4 *hi = reinterpret_cast<float4 *>(out + GC_LH + p);
+                       const float4 ea = lo[0], eb = lo[1];
+                       const float4 ta = *reinterpret_cast<const float4 *>(tw32p + p);
+                       const float4 tb = *reinterpret_cast<const float4 *>(tw32p + p + 2);
+                       const float2 o0 = cmul(x0, make_float2(ta.x, ta.y)), o1 = cmul(x1, make_float2(ta.z, ta.w));
+                       const float2 o2 = cmul(x2, make_float2(tb.x, tb.y)), o3 = cmul(x3, make_float2(tb.z, tb.w));
+                       lo[0] = make_float4(ea.x + o0.x, ea.y + o0.y, ea.z + o1.x, ea.w + o1.y);
+                       lo[1] = make_float4(eb.x + o2.x, eb.y + o2.y, eb.z + o3.x, eb.w + o3.y);
+                       hi[0] = make_float4(ea.x - o0.x, ea.y - o0.y, ea.z - o1.x, ea.w - o1.y);
+                       hi[1] = make_float4(eb.x - o2.x, eb.y - o2.y, eb.z - o3.x, eb.w - o3.y);
+                   },
+                   lds, tw16k, tid);
 }
 
 // acq_fwd: grid (bin, iteration, grid group)
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
     const GcChan *__restrict__ chan, const int *__restrict__ grid_chan, const double *__restrict__ freqs,
     const uint64_t *__restrict__ grid_wrpos, const float2 *__restrict__ tw16k,
-    const float2 *__restrict__ tw32k, float2 *__restrict__ X, int maxfreq, int maxintg)
+    const float2 *__restrict__ tw32p, float2 *__restrict__ X, int maxfreq, int maxintg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -142,13 +158,13 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
         return make_float2((float)I * sc, (float)Q * sc);
     };
     float2 *out = X + (((size_t)g * maxintg + it) * maxfreq + bin) * GC_L;
-    fwd32k_store(sample, lds, tw16k, tw32k, out, tid);
+    fwd32k_store(sample, lds, tw16k, tw32p, out, tid);
 }
 
 // acq_code: grid (channel)
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *__restrict__ chan,
                                                                   const float2 *__restrict__ tw16k,
-                                                                  const float2 *__restrict__ tw32k,
+                                                                  const float2 *__restrict__ tw32p,
                                                                   float2 *__restrict__ C)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *
         while (t >= clen) t -= clen;
         return make_float2((float)code[(int)t], 0.f);
     };
-    fwd32k_store(sample, lds, tw16k, tw32k, C + (size_t)ch * GC_L, tid);
+    fwd32k_store(sample, lds, tw16k, tw32p, C + (size_t)ch * GC_L, tid);
 }
 
 // ---- workgroup reductions used by acq_corr --------------------------------
@@ -211,12 +227,20 @@ __device__ __forceinline__ void wg_sum_max(double &s, double &m, double *sd, int
     for (int w = 1; w < NT / 64; w++) { s += sd[w]; m = fmax(m, sd[16 + w]); }
 }
 
-struct RawXC { float4 xa, xb, ca, cb; };
+struct RawXC { float4 la, lb, ha, hb, cla, clb, cha, chb; };     // X[f], X[f+L/2], C[f], C[f+L/2] at 4 positions
+struct RawXCT { RawXC r; float4 ta, tb; };                        // + their 32768-point twiddles
 
-// acq_corr: one workgroup of NT lanes per (bin, channel)
+// acq_corr: one workgroup of NT lanes per (bin, channel).
+// y = IFFT_L(Y), Y = X conj(C) (ref src/sdrcmn.c:236-246; the reference's extra minus sign vanishes
+// under |.|^2), split by lag parity so that each 16384-point transform ends in final values:
+//   y[2j]   = IFFT_16k( Y[f] + Y[f + L/2] )[j]
+//   y[2j+1] = IFFT_16k( (Y[f] - Y[f + L/2]) exp(+2 pi i f/L) )[j],   f < L/2.
+// Lags k < nsamp <= 16384 are wanted, i.e. j < 8192: of a lane's outputs j = o + 1024 q those with
+// q < 8.  Nothing has to wait for the other transform, so the only long-lived registers are the
+// power accumulators.
 template <int NT>
 __global__ __launch_bounds__(NT) void acq_corr_kernel(
-    const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32k,
+    const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32p,
     const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
     GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg, int nchg)
 {
@@ -238,12 +262,14 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     const float2 *Cc = C + (size_t)ch * GC_L;
     const float invL2 = 1.0f / ((float)GC_L * (float)GC_L);
 
-    // lane `tid` owns lags k = tid + NT*h + 1024*q (h < 1024/NT, q < 16): register index 16*h + q
-    constexpr int NP = 16 * (1024 / NT);
-    constexpr int CHUNK = 4;                       // butterflies whose operands are in flight together
+    // lane `tid` owns lags k = 2 (tid + NT*h + 1024*q) + par (par < 2, h < 1024/NT, q < 8):
+    // register index s = NPH*par + 8*h + q
+    constexpr int NPH = 8 * (1024 / NT), NP = 2 * NPH;
+    constexpr int CHUNK = 2;                       // butterflies whose operands are in flight together
     double P[NP];
 #pragma unroll
     for (int s = 0; s < NP; s++) P[s] = 0.0;
+    auto lag_of = [](int tid, int s) { return 2 * (tid + NT * ((s % NPH) >> 3) + 1024 * (s & 7)) + s / NPH; };
 
     for (int it = 0; it < nit; it++) {
         // Opaque copy of the lane id: keeps the address computations of one iteration from being
@@ -251,51 +277,75 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const float2 *Xb = X + (((size_t)c.grid * maxintg + it) * maxfreq + bin) * GC_L;
-        float2 e[NP];
-        // E = IFFT16k(Y[even f]), O = IFFT16k(Y[odd f]) with Y = X conj(C) (ref src/sdrcmn.c:236-240;
-        // the reference's extra minus sign vanishes under |.|^2); X, C and Y all in pass order
-        auto fetch = [&](const float2 *xp, const float2 *cp) {
-            return [xp, cp](int p) {
-                RawXC r;
-                r.xa = *reinterpret_cast<const float4 *>(xp + p);
-                r.xb = *reinterpret_cast<const float4 *>(xp + p + 2);
-                r.ca = *reinterpret_cast<const float4 *>(cp + p);
-                r.cb = *reinterpret_cast<const float4 *>(cp + p + 2);
-                return r;
-            };
+        auto load8 = [Xb, Cc](int p) {
+            RawXC r;
+            r.la = *reinterpret_cast<const float4 *>(Xb + p);
+            r.lb = *reinterpret_cast<const float4 *>(Xb + p + 2);
+            r.ha = *reinterpret_cast<const float4 *>(Xb + GC_LH + p);
+            r.hb = *reinterpret_cast<const float4 *>(Xb + GC_LH + p + 2);
+            r.cla = *reinterpret_cast<const float4 *>(Cc + p);
+            r.clb = *reinterpret_cast<const float4 *>(Cc + p + 2);
+            r.cha = *reinterpret_cast<const float4 *>(Cc + GC_LH + p);
+            r.chb = *reinterpret_cast<const float4 *>(Cc + GC_LH + p + 2);
+            return r;
         };
-        auto product = [](const RawXC &r, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
-            x0 = cmulc(make_float2(r.xa.x, r.xa.y), make_float2(r.ca.x, r.ca.y));
-            x1 = cmulc(make_float2(r.xa.z, r.xa.w), make_float2(r.ca.z, r.ca.w));
-            x2 = cmulc(make_float2(r.xb.x, r.xb.y), make_float2(r.cb.x, r.cb.y));
-            x3 = cmulc(make_float2(r.xb.z, r.xb.w), make_float2(r.cb.z, r.cb.w));
-        };
-        gcfft::dit<+1, NT, CHUNK>(fetch(Xb, Cc), product,
+        // Y[f] = X[f] conj(C[f]) at the four positions of a butterfly, low and high half of the spectrum
+#define GC_YLO(r, k) cmulc(make_float2((k) < 2 ? ((k) & 1 ? (r).la.z : (r).la.x) : ((k) & 1 ? (r).lb.z : (r).lb.x), \
+                                       (k) < 2 ? ((k) & 1 ? (r).la.w : (r).la.y) : ((k) & 1 ? (r).lb.w : (r).lb.y)), \
+                           make_float2((k) < 2 ? ((k) & 1 ? (r).cla.z : (r).cla.x) : ((k) & 1 ? (r).clb.z : (r).clb.x), \
+                                       (k) < 2 ? ((k) & 1 ? (r).cla.w : (r).cla.y) : ((k) & 1 ? (r).clb.w : (r).clb.y)))
+#define GC_YHI(r, k) cmulc(make_float2((k) < 2 ? ((k) & 1 ? (r).ha.z : (r).ha.x) : ((k) & 1 ? (r).hb.z : (r).hb.x), \
+                                       (k) < 2 ? ((k) & 1 ? (r).ha.w : (r).ha.y) : ((k) & 1 ? (r).hb.w : (r).hb.y)), \
+                           make_float2((k) < 2 ? ((k) & 1 ? (r).cha.z : (r).cha.x) : ((k) & 1 ? (r).chb.z : (r).chb.x), \
+                                       (k) < 2 ? ((k) & 1 ? (r).cha.w : (r).cha.y) : ((k) & 1 ? (r).chb.w : (r).chb.y)))
+        // even lags
+        gcfft::dit<+1, NT, CHUNK>(load8,
+                       [&](const RawXC &r, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+                           x0 = cadd(GC_YLO(r, 0), GC_YHI(r, 0));
+                           x1 = cadd(GC_YLO(r, 1), GC_YHI(r, 1));
+                           x2 = cadd(GC_YLO(r, 2), GC_YHI(r, 2));
+                           x3 = cadd(GC_YLO(r, 3), GC_YHI(r, 3));
+                       },
                        [&](int h, int, float2 (&a)[16]) {
 #pragma unroll
-                           for (int q = 0; q < 16; q++) e[16 * h + q] = a[q];
-                       },
-                       lds, tw16k, tid);
-        __syncthreads();
-        // y[k] = E[k] + conj(w^k) O[k]; P[k] += |y|^2 / L^2 (ref src/sdrcmn.c:244-246 with the
-        // reference's m-point scaling folded: (m/L)^2/m^2 = 1/L^2)
-        gcfft::dit<+1, NT, CHUNK>(fetch(Xb + GC_LH, Cc + GC_LH), product,
-                       [&](int h, int o, float2 (&a)[16]) {
-#pragma unroll
-                           for (int q = 0; q < 16; q++) {
-                               const int k = o + 1024 * q;
-                               const float2 y = cadd(e[16 * h + q], cmulc(a[q], tw32k[k]));
-                               const float pw = fmaf(y.x, y.x, y.y * y.y) * invL2;
-                               P[16 * h + q] += (double)pw;
+                           for (int q = 0; q < 8; q++) {
+                               const float pw = fmaf(a[q].x, a[q].x, a[q].y * a[q].y) * invL2;
+                               P[8 * h + q] += (double)pw;      // (ref :244-246 with the m-point scaling folded)
                            }
                        },
                        lds, tw16k, tid);
+        __syncthreads();
+        asm volatile("" : "+v"(tid));            // (as above: the second transform recomputes its addresses)
+        // odd lags; exp(+2 pi i f/L) = conj of the forward twiddle
+        gcfft::dit<+1, NT, CHUNK>([&](int p) {
+                           RawXCT t;
+                           t.r = load8(p);
+                           t.ta = *reinterpret_cast<const float4 *>(tw32p + p);
+                           t.tb = *reinterpret_cast<const float4 *>(tw32p + p + 2);
+                           return t;
+                       },
+                       [&](const RawXCT &t, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+                           x0 = cmulc(csub(GC_YLO(t.r, 0), GC_YHI(t.r, 0)), make_float2(t.ta.x, t.ta.y));
+                           x1 = cmulc(csub(GC_YLO(t.r, 1), GC_YHI(t.r, 1)), make_float2(t.ta.z, t.ta.w));
+                           x2 = cmulc(csub(GC_YLO(t.r, 2), GC_YHI(t.r, 2)), make_float2(t.tb.x, t.tb.y));
+                           x3 = cmulc(csub(GC_YLO(t.r, 3), GC_YHI(t.r, 3)), make_float2(t.tb.z, t.tb.w));
+                       },
+                       [&](int h, int, float2 (&a)[16]) {
+#pragma unroll
+                           for (int q = 0; q < 8; q++) {
+                               const float pw = fmaf(a[q].x, a[q].x, a[q].y * a[q].y) * invL2;
+                               P[NPH + 8 * h + q] += (double)pw;
+                           }
+                       },
+                       lds, tw16k, tid);
+#undef GC_YLO
+#undef GC_YHI
 
         // row statistics for checkacquisition()
         MaxIdx m; m.v = -1.0; m.k = 0x7fffffff;
 #pragma unroll
         for (int s = 0; s < NP; s++) {
-            const int k = tid + NT * (s >> 4) + 1024 * (s & 15);
+            const int k = lag_of(tid, s);
             if (k < n) { MaxIdx t; t.v = P[s]; t.k = k; m = better(m, t); }
         }
         m = wg_argmax<NT>(m, sd, si, tid);
@@ -304,7 +354,7 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
         double so = 0.0, mo = -1.0;
 #pragma unroll
         for (int s = 0; s < NP; s++) {
-            const int k = tid + NT * (s >> 4) + 1024 * (s & 15);
+            const int k = lag_of(tid, s);
             if (k < n) {
                 const bool outside = (exs <= exe) ? (k < exs || k > exe) : (k < exs && k > exe);
                 if (outside) so += P[s];
@@ -322,7 +372,7 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     if (Pout) {
 #pragma unroll
         for (int s = 0; s < NP; s++) {
-            const int k = tid0 + NT * (s >> 4) + 1024 * (s & 15);
+            const int k = lag_of(tid0, s);
             if (k < n) Pout[(size_t)bin * n + k] = P[s];
         }
     }
@@ -429,7 +479,7 @@ void gc_acq_free(gnsscorr_ctx *ctx)
 {
     GcAcqWork *w = ctx->acq;
     if (!w) return;
-    hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
+    hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->tw32p); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
     hipFree(w->iters); hipFree(w->res); hipFree(w->P);
     hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos);
     delete w;
@@ -443,7 +493,8 @@ static int acq_tables(gnsscorr_ctx *ctx)
     if (w->tw16k) return GNSSCORR_OK;
     GC_HIP(hipMalloc((void **)&w->tw16k, sizeof(float2) * GC_LH));
     GC_HIP(hipMalloc((void **)&w->tw32k, sizeof(float2) * GC_LH));
-    hipLaunchKernelGGL(tw_init_kernel, dim3(GC_LH / 256), dim3(256), 0, ctx->stream, w->tw16k, w->tw32k);
+    GC_HIP(hipMalloc((void **)&w->tw32p, sizeof(float2) * GC_LH));
+    hipLaunchKernelGGL(tw_init_kernel, dim3(GC_LH / 256), dim3(256), 0, ctx->stream, w->tw16k, w->tw32k, w->tw32p);
     GC_HIP(hipGetLastError());
     {
         const int lds = GC_FFT_LDS + 256;
@@ -488,7 +539,7 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     {
         GcTimed t(ctx, "acq_code");
         hipLaunchKernelGGL(acq_code_kernel, dim3(nch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
-                           ctx->dchan, w->tw16k, w->tw32k, w->C);
+                           ctx->dchan, w->tw16k, w->tw32p, w->C);
     }
     GC_HIP(hipGetLastError());
     GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -521,7 +572,7 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     {
         GcTimed t(ctx, "acq_fwd");
         hipLaunchKernelGGL(acq_fwd_kernel, dim3(w->maxfreq, w->maxintg, w->ngrid), dim3(GC_FFT_THREADS), lds,
-                           ctx->stream, ctx->dchan, w->d_grid_chan, ctx->dfreqs, w->d_grid_wrpos, w->tw16k, w->tw32k,
+                           ctx->stream, ctx->dchan, w->d_grid_chan, ctx->dfreqs, w->d_grid_wrpos, w->tw16k, w->tw32p,
                            w->X, w->maxfreq, w->maxintg);
     }
     GC_HIP(hipGetLastError());
@@ -532,11 +583,11 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
         static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
         if (nt == 1024)
             hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(1024), lds + 256,
-                               ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows,
+                               ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
         else
             hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(512), lds + 256,
-                               ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows,
+                               ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
     }
     GC_HIP(hipGetLastError());
@@ -578,7 +629,7 @@ extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
     // iteration count of the last run is still in w->iters[ch]; rows of this channel are rewritten
     // with identical values
     hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
-                       ctx->stream, ctx->dchan, w->tw16k, w->tw32k, w->X, w->C, w->iters, w->rows, w->P, ch,
+                       ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows, w->P, ch,
                        w->maxfreq, w->maxintg, 1);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
