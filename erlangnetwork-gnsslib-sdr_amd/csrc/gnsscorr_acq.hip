@@ -378,13 +378,14 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     }
 }
 
-// acq_final: one lane per channel walks iterations and bins
-__global__ void acq_final_kernel(const GcChan *__restrict__ chan, const double *__restrict__ freqs,
-                                 const GcAcqRow *__restrict__ rows, const uint64_t *__restrict__ grid_wrpos,
-                                 gnsscorr_acqres_t *__restrict__ res, int *__restrict__ iters_out, int nch,
-                                 int maxfreq, int maxintg)
+// acq_final: one wavefront per channel; the lanes share the bins of an iteration
+__global__ __launch_bounds__(64) void acq_final_kernel(const GcChan *__restrict__ chan, const double *__restrict__ freqs,
+                                                       const GcAcqRow *__restrict__ rows,
+                                                       const uint64_t *__restrict__ grid_wrpos,
+                                                       gnsscorr_acqres_t *__restrict__ res, int *__restrict__ iters_out,
+                                                       int nch, int maxfreq, int maxintg)
 {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.x, lane = threadIdx.x;
     if (ch >= nch) return;
     const GcChan &c = chan[ch];
     const int n = c.nsamp;
@@ -394,9 +395,20 @@ __global__ void acq_final_kernel(const GcChan *__restrict__ chan, const double *
     int it = 0;
     for (; it < c.intg; it++) {
         const GcAcqRow *row = rows + ((size_t)ch * maxintg + it) * maxfreq;
-        int fi = 0;
-        for (int b = 1; b < c.nfreq; b++)
-            if (row[b].rowmax > row[fi].rowmax) fi = b;         // lowest flat index wins ties
+        // best row: largest rowmax, lowest flat index (= lowest bin) on ties
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int b = lane; b < c.nfreq; b += 64) {
+            const double v = row[b].rowmax;
+            if (v > bv) { bv = v; bi = b; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(bv, d);
+            const int oi = __shfl_xor(bi, d);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const int fi = bi;
         const GcAcqRow w = row[fi];
         const int ne = 4 * c.nsampchip + 1;                     // samples inside the excluded window
         const double meanP = w.sum_out / (double)(n - ne);
@@ -410,8 +422,10 @@ __global__ void acq_final_kernel(const GcChan *__restrict__ chan, const double *
     r.iters = r.flagacq ? it + 1 : c.intg;
     // ref src/sdracq.c:51-53 / :62
     r.buffloc = r.flagacq ? b0 + (uint64_t)r.acqcodei : b0 + (uint64_t)c.intg * n;
-    res[ch] = r;
-    if (iters_out) iters_out[ch] = r.iters;
+    if (lane == 0) {
+        res[ch] = r;
+        if (iters_out) iters_out[ch] = r.iters;
+    }
 }
 
 __global__ void fill_int_kernel(int *p, const GcChan *__restrict__ chan, int nch)
@@ -593,7 +607,7 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     GC_HIP(hipGetLastError());
     {
         GcTimed t(ctx, "acq_final");
-        hipLaunchKernelGGL(acq_final_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->dchan,
+        hipLaunchKernelGGL(acq_final_kernel, dim3(ctx->nch), dim3(64), 0, ctx->stream, ctx->dchan,
                            ctx->dfreqs, w->rows, w->d_grid_wrpos, w->res, w->iters, ctx->nch, w->maxfreq,
                            w->maxintg);
     }
