@@ -249,13 +249,14 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 32 doubles
     int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 256);       // 16 ints
     // Workgroup order (speed only): blocks b, b+8, b+16, ... tend to share an XCD, so each XCD walks
-    // one Doppler bin across all channels before the next bin: the bin's forward spectra are pulled
-    // into that XCD's L2 once per iteration and shared by every SV.
+    // the Doppler bins of one channel before the next channel: the channel's code spectrum (256 KB)
+    // stays in that XCD's L2 for all its bins and iterations, and the forward spectra -- read once per
+    // (bin, channel) either way -- stream from the Infinity Cache, which holds all of them (186 MB).
     const int tid0 = threadIdx.x;
     const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int bin = (qq / nchg) * 8 + slot;
-    const int ch = Pout ? pout_ch : qq % nchg;
-    if (bin >= maxfreq) return;
+    const int bin = Pout ? qq * 8 + slot : qq % maxfreq;
+    const int ch = Pout ? pout_ch : (qq / maxfreq) * 8 + slot;
+    if (bin >= maxfreq || (!Pout && ch >= nchg)) return;
     const GcChan &c = chan[ch];
     if (bin >= c.nfreq) return;
     const int n = c.nsamp, nit = iters[ch], nsc2 = 2 * c.nsampchip;
@@ -596,11 +597,11 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
         GcTimed t(ctx, "acq_corr");
         static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
         if (nt == 1024)
-            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(1024), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(1024), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
         else
-            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((w->maxfreq + 7) / 8) * ctx->nch), dim3(512), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(512), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
     }

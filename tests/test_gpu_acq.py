@@ -84,6 +84,7 @@ def test_acquisition_matches_oracle(gc, orc, synth, engine, dtype, f_if):
             # true Doppler within one 200 Hz bin, code phase consistent with the generator
             s = [s for s in sats if s["prn"] == 3][0]
             assert abs((r["acqfreq"] - f_if) - s["doppler"]) <= 200.0
+        if p in (3, 20):        # the full power array of the first and of the last channel
             P = engine.acq_power(i)
             assert P.shape == (o.nfreq, o.nsamp)
             assert rel_err(P.ravel(), power) <= 1e-4
