@@ -110,8 +110,12 @@ int  gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch,
                             gnsscorr_trkstate_t *st);
 /* Correlate `nepoch` consecutive code periods of every channel with the
  * frequencies held (as between two loop-filter updates, ref
- * src/sdrmain.c:272-302).  Asynchronous on the context's stream; advances the
- * device-resident state. */
+ * src/sdrmain.c:272-302).  Asynchronous; advances the device-resident state.
+ * The correlator launches go to the context's stream back to back; the
+ * planner (next batch) and the conversion of the partial sums into the
+ * result arrays run on streams of the context's own.  gnsscorr_sync,
+ * gnsscorr_trk_fetch*, gnsscorr_trk_get_state and gnsscorr_trk_devptrs order
+ * the caller behind them. */
 int  gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch);
 /* Results of the last gnsscorr_trk_run, [nch][nepoch][1+2*corrn] each, in the
  * reference's tap order {P,E1,L1,E2,L2,...}.  trkII / trkQQ are what
@@ -124,7 +128,9 @@ int  gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQQ,
 /* cumsumcorr() over the epochs of the last run (ref src/sdrtrk.c:64-76):
  * sumI/sumQ [nch][1+2*corrn] */
 int  gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ);
-/* device pointers to the result arrays of the last run (layout as fetch) */
+/* device pointers to the result arrays of the last run (layout as fetch);
+ * work queued on the context's stream after this call sees the results of
+ * every gnsscorr_trk_run issued before it */
 int  gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ);
 
 /* ---- acquisition: parallel code phase search --------------------------------
