@@ -156,7 +156,7 @@ def cpu_baseline_acq(orc, data, ringlen, wrpos, chans, seconds_budget=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=1000, help="code periods per channel per step")
     ap.add_argument("--acq-steps", type=int, default=5)
