@@ -154,3 +154,31 @@ def test_fine_doppler_grid_and_10ms_sums(gc, orc, synth, engine):
         assert np.array_equal(np.ctypeslib.as_array(o.sumI)[:5], sI[i])
         assert np.array_equal(np.ctypeslib.as_array(o.sumQ)[:5], sQ[i])
         assert np.array_equal(sI[i], II[i].sum(axis=0)) and np.array_equal(sQ[i], QQ[i].sum(axis=0))
+
+
+def test_mixed_sample_formats_in_one_engine(gc, orc, engine):
+    """IQ channels on front end 1 and real-IF channels on front end 2 in one batch: one correlator launch
+    per sample format, each serving only its own channels."""
+    from test_gpu_tracking import _oracle_run
+    rng = np.random.default_rng(5150)
+    nsamp = 16 * 8192
+    d_iq = rng.integers(-70, 71, size=(nsamp, 2), dtype=np.int8)
+    d_re = rng.integers(-90, 91, size=nsamp, dtype=np.int8)
+    engine.ring_create(1, 2, nsamp)
+    engine.ring_create(2, 1, nsamp)
+    engine.ring_push_raw(1, d_iq, nsamp)
+    engine.ring_push_raw(2, d_re, nsamp)
+    spec = [(4, 2, 1, 0.0), (9, 1, 2, 4.092e6), (21, 2, 1, 0.0), (30, 1, 2, 4.092e6)]     # prn, dtype, ftype, f_if
+    chans = [gc.Channel(p, dtype=dt, ftype=ft, f_if=fi) for p, dt, ft, fi in spec]
+    engine.set_channels(chans)
+    states = [dict(carrfreq=fi + float(rng.uniform(-4000, 4000)), codefreq=c.crate + float(rng.uniform(-2, 2)),
+                   remcode=float(rng.uniform(0.05, 0.95)), remcarr=float(rng.uniform(0, 6)), buffloc=77 + 500 * i)
+              for i, (c, (_, _, _, fi)) in enumerate(zip(chans, spec))]
+    engine.trk_set_state(states)
+    engine.trk_run(5)
+    II, QQ, ns = engine.trk_fetch()
+    for i, (p, dt, ft, fi) in enumerate(spec):
+        o = orc.make_chan(p, dtype=dt, f_if=fi)
+        oII, oQQ, ons, _ = _oracle_run(orc, [o], [states[i]], d_iq if dt == 2 else d_re, nsamp, nsamp, 5, mode=1)
+        assert np.array_equal(ns[i], ons[0])
+        assert np.array_equal(II[i], oII[0]) and np.array_equal(QQ[i], oQQ[0])
