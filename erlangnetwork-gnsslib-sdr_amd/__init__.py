@@ -126,7 +126,7 @@ EXPORTS_GNSSCORR = [
     "gnsscorr_ring_commit", "gnsscorr_ring_wrpos", "gnsscorr_ring_devptr", "gnsscorr_set_channels",
     "gnsscorr_num_channels", "gnsscorr_trk_set_state", "gnsscorr_trk_get_state", "gnsscorr_trk_run",
     "gnsscorr_trk_fetch", "gnsscorr_trk_fetch_sums", "gnsscorr_trk_devptrs", "gnsscorr_acq_run",
-    "gnsscorr_acq_fetch", "gnsscorr_acq_power", "gnsscorr_fft16k", "gnsscorr_pspec",
+    "gnsscorr_acq_fetch", "gnsscorr_trk_start_from_acq", "gnsscorr_acq_power", "gnsscorr_fft16k", "gnsscorr_pspec",
     "gnsscorr_timing_enable", "gnsscorr_timing_read", "gnsscorr_timing_reset", "gnsscorr_default_ctx"]
 EXPORTS_SDR = [
     "sdracquisition", "checkacquisition", "sdrtracking", "cumsumcorr", "clearcumsumcorr", "pll", "dll",
@@ -171,6 +171,7 @@ def lib():
     L.gnsscorr_trk_devptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.gnsscorr_acq_run.argtypes = [C.c_void_p, C.c_uint64]
     L.gnsscorr_acq_fetch.argtypes = [C.c_void_p, C.POINTER(AcqRes)]
+    L.gnsscorr_trk_start_from_acq.argtypes = [C.c_void_p]
     L.gnsscorr_acq_power.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.gnsscorr_fft16k.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.gnsscorr_pspec.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -388,6 +389,9 @@ class Engine:
         _check(self._L.gnsscorr_acq_fetch(self.h, arr))
         return [dict(acqcodei=a.acqcodei, freqi=a.freqi, acqfreq=a.acqfreq, cn0=a.cn0, peakr=a.peakr,
                      flagacq=a.flagacq, iters=a.iters, buffloc=a.buffloc) for a in arr]
+
+    def trk_start_from_acq(self):
+        _check(self._L.gnsscorr_trk_start_from_acq(self.h))
 
     def acq_power(self, ch):
         c = self.channels[ch]

@@ -628,6 +628,37 @@ extern "C" int gnsscorr_acq_fetch(gnsscorr_ctx *ctx, gnsscorr_acqres_t *res)
     return GNSSCORR_OK;
 }
 
+// Acquired channels start tracking where sdracquisition() leaves them (ref src/sdracq.c:51-55:
+// trk.carrfreq = acq.acqfreq, trk.codefreq = crate, code and carrier remainders zero, tracking from the
+// returned buffloc); channels that were not acquired keep their state.
+__global__ void acq_to_trk_kernel(const GcChan *__restrict__ chan, const gnsscorr_acqres_t *__restrict__ res,
+                                  GcTrkState *__restrict__ state, int nch)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch || !res[ch].flagacq) return;
+    GcTrkState s;
+    s.carrfreq = res[ch].acqfreq;
+    s.codefreq = chan[ch].crate;
+    s.remcode = 0.0;
+    s.remcarr = 0.0;
+    s.buffloc = res[ch].buffloc;
+    state[ch] = s;
+}
+
+extern "C" int gnsscorr_trk_start_from_acq(gnsscorr_ctx *ctx)
+{
+    if (!ctx || !ctx->acq || !ctx->acq->ran) return gc_fail(GNSSCORR_ESTATE, "trk_start_from_acq: no acq_run yet");
+    GC_HIP(hipSetDevice(ctx->device));
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    ctx->ahead_valid = false;                                         // ... and is dropped
+    ctx->state_touched = true;
+    hipLaunchKernelGGL(acq_to_trk_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->dchan,
+                       ctx->acq->res, ctx->dstate2[ctx->state_cur], ctx->nch);
+    GC_HIP(hipGetLastError());
+    return GNSSCORR_OK;
+}
+
 extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
 {
     if (!ctx || !ctx->acq || !ctx->acq->ran) return gc_fail(GNSSCORR_ESTATE, "acq_power: no acq_run yet");

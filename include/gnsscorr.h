@@ -149,6 +149,11 @@ typedef struct {
 /* wrpos == 0: use each ring's current write position.  Asynchronous. */
 int  gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos);
 int  gnsscorr_acq_fetch(gnsscorr_ctx *ctx, gnsscorr_acqres_t *res);
+/* Device-side hand-over of the last gnsscorr_acq_run to tracking: every acquired
+ * channel gets the state sdracquisition() leaves behind (ref src/sdracq.c:51-55:
+ * carrfreq = acqfreq, codefreq = crate, remcode = remcarr = 0, buffloc = the
+ * returned sample index); channels not acquired keep theirs.  Asynchronous. */
+int  gnsscorr_trk_start_from_acq(gnsscorr_ctx *ctx);
 /* The reference's `power` array for one channel: nfreq*nsamp doubles,
  * accumulated over res.iters iterations (re-runs the search for that channel
  * with the iteration count of the last gnsscorr_acq_run). */

@@ -73,6 +73,17 @@ def test_gps_plus_glonass_on_two_streams(gc, orc, synth, engine):
     for c, r, s in zip(chans[3:], res[3:], sat2):
         assert abs(r["acqfreq"] - s["doppler"]) <= 100.0 + 1e-6
 
+    # device-side hand-over: acquired channels take over the acquisition result, the others keep their state
+    parked = [dict(carrfreq=1.0 + i, codefreq=chans[i].crate, remcode=0.25, remcarr=0.5, buffloc=1000 + i)
+              for i in range(len(chans))]
+    engine.trk_set_state(parked)
+    engine.trk_start_from_acq()
+    for i, (st, r) in enumerate(zip(engine.trk_get_state(), res)):
+        if r["flagacq"]:
+            assert st == dict(carrfreq=r["acqfreq"], codefreq=chans[i].crate, remcode=0.0, remcarr=0.0, buffloc=r["buffloc"])
+        else:
+            assert st == parked[i]
+
     # tracking batch of every acquired channel from its acquisition result (ref src/sdracq.c:54-55)
     live = [i for i, r in enumerate(res) if r["flagacq"]]
     states = [dict(carrfreq=res[i]["acqfreq"], codefreq=chans[i].crate, remcode=0.0, remcarr=0.0,
