@@ -261,8 +261,10 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
             return gc_fail(GNSSCORR_EINVAL, "channel %d: corrn differs (one [TRACK] CORRN per receiver)", i);
         if (c.nfreq < 1 || c.nfreq > GNSSCORR_MAXFREQ || !c.freq)
             return gc_fail(GNSSCORR_EINVAL, "channel %d: nfreq %d", i, c.nfreq);
-        if (c.nsamp <= 0 || c.nsamp > 16384)
-            return gc_fail(GNSSCORR_EINVAL, "channel %d: nsamp %d (acquisition FFT supports <= 16384)", i, c.nsamp);
+        // tracking takes any period length the int32 accumulators hold; acquisition (gnsscorr_acq_run)
+        // additionally needs nsamp <= 16384 for its 32768-point transform and says so itself
+        if (c.nsamp <= 0 || c.nsamp > 262144)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: nsamp %d (1..262144 supported)", i, c.nsamp);
         for (int k = 0; k < c.corrn; k++)
             if (c.corrp[k] <= 0 || (k && c.corrp[k] <= c.corrp[k - 1]))
                 return gc_fail(GNSSCORR_EINVAL, "channel %d: corrp must be positive and increasing", i);

@@ -273,3 +273,30 @@ def test_planner_chain_long_batch(gc, orc, engine):
     for a, b in zip(fin, ofin):
         assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+
+
+def test_trk_20msps_period(gc, orc, engine):
+    """A 20 Msps front end (ref frontend/stereo_L1G1.ini): 20000 samples per code period, five rounds of the
+    correlator per period.  Acquisition of such a stream needs a longer transform than this build has and
+    must say so instead of returning something."""
+    f_sf = 20e6
+    nsamples = 20000 * 8
+    rng = np.random.default_rng(2000)
+    data = rng.integers(-100, 101, size=(nsamples, 2), dtype=np.int8)
+    engine.ring_create(1, 2, nsamples)
+    engine.ring_push_raw(1, data, nsamples)
+    chans = [gc.Channel(p, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for p in (7, 24)]
+    assert chans[0].nsamp == 20000
+    engine.set_channels(chans)
+    states = [dict(carrfreq=float(rng.uniform(-3000, 3000)), codefreq=c.crate + float(rng.uniform(-1, 1)),
+                   remcode=float(rng.uniform(0.1, 0.9)), remcarr=float(rng.uniform(0, 6)), buffloc=11 + 300 * i)
+              for i, c in enumerate(chans)]
+    engine.trk_set_state(states)
+    engine.trk_run(5)
+    II, QQ, ns = engine.trk_fetch()
+    ochs = [orc.make_chan(c.prn, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for c in chans]
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 5, mode=1)
+    assert np.array_equal(ns, ons) and ns[:, 1:].min() >= 19999      # (the first period is cut by remcode)
+    assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+    with pytest.raises(gc.GnsscorrError):
+        engine.acq_run(12 * 20000)
