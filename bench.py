@@ -104,7 +104,7 @@ def cpu_baseline_tracking(orc, data, ringlen, chans, states, seconds_budget=12.0
         o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
         b = st["buffloc"]
         for _ in range(nepoch):
-            L.orc_sdrtracking(C.byref(o), C.byref(ring), b, 0)
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), b)
             b += o.currnsamp
         return nepoch
 
@@ -140,7 +140,7 @@ def cpu_baseline_acq(orc, data, ringlen, wrpos, chans, seconds_budget=12.0):
         freq = np.ctypeslib.as_array(o.freq)[:nf].copy()
         t = time.time()
         L.orc_pcorrelator(buf.ctypes.data, 2, o.ti, n, freq.ctypes.data, nf, o.crate, o.nfft, xc.ctypes.data,
-                          P.ctypes.data, 0)
+                          P.ctypes.data)
         return time.time() - t
 
     nsv = ncores            # one pcorrelator() call (71 bins, 1 iteration) per core

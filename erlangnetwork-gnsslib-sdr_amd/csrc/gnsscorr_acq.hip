@@ -39,7 +39,19 @@ using gcfft::cmul;
 using gcfft::cmulc;
 using gcfft::csub;
 
+// Carrier NCO of one Doppler bin over the 2*nsamp acquisition window, phase 0 at its first sample
+// (ref src/sdrcmn.c:761): the reference's running sum as a piece table (gnsscorr_nco.h)
+struct GcAcqCar {
+    int n, pad;
+    int k0[GC_NCAR];
+    GcCarSeg seg[GC_NCAR];
+};
+
+#define GC_ACQ_CARLDS (((GC_NCAR * 4 + 15) & ~15) + GC_NCAR * (int)sizeof(GcCarSeg))
+
 struct GcAcqWork {
+    GcAcqCar *car = nullptr;    // [grid][bin]
+    int *car_overflow = nullptr;
     float2 *tw16k = nullptr;    // exp(-2 pi i t/16384), t < 16384
     float2 *tw32k = nullptr;    // exp(-2 pi i t/32768), t < 16384
     float2 *tw32p = nullptr;    // the same twiddles in pass order: exp(-2 pi i freq_of(p)/32768), p < 16384
@@ -116,9 +128,27 @@ __device__ __forceinline__ void fwd32k_store(F sample, float2 *lds, const float2
                    lds, tw16k, tid);
 }
 
+// one lane per (grid, bin): the bin's carrier piece table
+__global__ void acq_nco_kernel(const GcChan *__restrict__ chan, const int *__restrict__ grid_chan,
+                               const double *__restrict__ freqs, GcAcqCar *__restrict__ car, int ngrid, int maxfreq,
+                               int *__restrict__ overflow)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngrid * maxfreq) return;
+    const GcChan &c = chan[grid_chan[i / maxfreq]];
+    const int bin = i % maxfreq;
+    GcAcqCar *t = car + i;
+    t->n = 0;
+    if (bin >= c.nfreq) return;
+    GcCarTable ct{t->k0, t->seg, GC_NCAR, 0, 0};
+    gc_carrier_walk(gc_carrier_phis(0.0), gc_carrier_ps(freqs[c.freq_off + bin], c.ti), 2 * c.nsamp, ct);
+    t->n = ct.n;
+    if (ct.overflow) atomicAdd(overflow, 1);
+}
+
 // acq_fwd: grid (bin, iteration, grid group)
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
-    const GcChan *__restrict__ chan, const int *__restrict__ grid_chan, const double *__restrict__ freqs,
+    const GcChan *__restrict__ chan, const int *__restrict__ grid_chan, const GcAcqCar *__restrict__ car,
     const uint64_t *__restrict__ grid_wrpos, const float2 *__restrict__ tw16k,
     const float2 *__restrict__ tw32p, float2 *__restrict__ X, int maxfreq, int maxintg)
 {
@@ -133,17 +163,20 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
     const uint64_t base = buffloc % c.ringlen;
     const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringlen = c.ringlen;
-    uint64_t A0, PS;
-    int kflip, neg;
-    gc_carrier_fx(0.0, freqs[c.freq_off + bin], c.ti, &A0, &PS, &kflip, &neg);   // phase starts at 0 (:761)
-    const uint64_t bias = (neg & 2) ? GC_FX_BIAS : 0ULL;
+    // the bin's carrier table (phase starts at 0 for every bin and iteration, :761) behind the FFT image
+    int *lk0 = reinterpret_cast<int *>(smem + GC_FFT_LDS + 256);
+    GcCarSeg *lseg = reinterpret_cast<GcCarSeg *>(smem + GC_FFT_LDS + 256 + ((GC_NCAR * 4 + 15) & ~15));
+    const GcAcqCar *gt = car + (size_t)g * maxfreq + bin;
+    const int ncar = gt->n;
+    if (tid < ncar) { lk0[tid] = gt->k0[tid]; lseg[tid] = gt->seg[tid]; }
+    __syncthreads();
     const float sc = (float)((1.0 / 32.0) / (double)c.nfft);     // CSCALE/m, ref src/sdrcmn.c:764
 
     auto sample = [&](int s) -> float2 {
         if (s >= n2) return make_float2(0.f, 0.f);
         uint64_t pos = base + (uint64_t)s;
         if (pos >= ringlen) pos -= ringlen;
-        const int idx = (int)(((uint64_t)s * PS + bias) >> 59);
+        const int idx = gc_carrier_idx_at(lk0, lseg, ncar, s);
         const int cs_ = aCos32[idx], sn_ = aSin32[idx];
         int I, Q;
         if (dtype == 2) {
@@ -496,7 +529,7 @@ void gc_acq_free(gnsscorr_ctx *ctx)
     if (!w) return;
     hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->tw32p); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
     hipFree(w->iters); hipFree(w->res); hipFree(w->P);
-    hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos);
+    hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos); hipFree(w->car); hipFree(w->car_overflow);
     delete w;
     ctx->acq = nullptr;
 }
@@ -513,7 +546,7 @@ static int acq_tables(gnsscorr_ctx *ctx)
     GC_HIP(hipGetLastError());
     {
         const int lds = GC_FFT_LDS + 256;
-        GC_HIP(hipFuncSetAttribute((const void *)acq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds + GC_ACQ_CARLDS));
         GC_HIP(hipFuncSetAttribute((const void *)acq_code_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
         GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
@@ -551,13 +584,25 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&w->d_grid_wrpos, sizeof(uint64_t) * w->ngrid));
     GC_HIP(hipMemcpyAsync(w->d_grid_chan, w->grid_chan.data(), sizeof(int) * w->ngrid, hipMemcpyHostToDevice,
                           ctx->stream));
+    GC_HIP(hipMalloc((void **)&w->car, sizeof(GcAcqCar) * (size_t)w->ngrid * w->maxfreq));
+    GC_HIP(hipMalloc((void **)&w->car_overflow, sizeof(int)));
+    GC_HIP(hipMemsetAsync(w->car_overflow, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(acq_nco_kernel, dim3((w->ngrid * w->maxfreq + 63) / 64), dim3(64), 0, ctx->stream, ctx->dchan,
+                       w->d_grid_chan, ctx->dfreqs, w->car, w->ngrid, w->maxfreq, w->car_overflow);
+    GC_HIP(hipGetLastError());
     {
         GcTimed t(ctx, "acq_code");
         hipLaunchKernelGGL(acq_code_kernel, dim3(nch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
                            ctx->dchan, w->tw16k, w->tw32p, w->C);
     }
     GC_HIP(hipGetLastError());
+    int over = 0;
+    GC_HIP(hipMemcpyAsync(&over, w->car_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (over) {
+        hipFree(w->C); w->C = nullptr;       // not prepared
+        return gc_fail(GNSSCORR_EINVAL, "acquisition: %d Doppler bins need more carrier NCO pieces than the tables hold", over);
+    }
     return GNSSCORR_OK;
 }
 
@@ -586,8 +631,8 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     const int lds = GC_FFT_LDS + 256;
     {
         GcTimed t(ctx, "acq_fwd");
-        hipLaunchKernelGGL(acq_fwd_kernel, dim3(w->maxfreq, w->maxintg, w->ngrid), dim3(GC_FFT_THREADS), lds,
-                           ctx->stream, ctx->dchan, w->d_grid_chan, ctx->dfreqs, w->d_grid_wrpos, w->tw16k, w->tw32p,
+        hipLaunchKernelGGL(acq_fwd_kernel, dim3(w->maxfreq, w->maxintg, w->ngrid), dim3(GC_FFT_THREADS), lds + GC_ACQ_CARLDS,
+                           ctx->stream, ctx->dchan, w->d_grid_chan, w->car, w->d_grid_wrpos, w->tw16k, w->tw32p,
                            w->X, w->maxfreq, w->maxintg);
     }
     GC_HIP(hipGetLastError());

@@ -90,8 +90,10 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     for (int i = 0; i < 2; i++) {
         hipFree(ctx->dunit2[i]); ctx->dunit2[i] = nullptr;
         hipFree(ctx->drounds2[i]); ctx->drounds2[i] = nullptr;
+        hipFree(ctx->dsegs2[i]); ctx->dsegs2[i] = nullptr;
         hipFree(ctx->dnsamp2[i]); ctx->dnsamp2[i] = nullptr;
     }
+    hipFree(ctx->dnco_overflow); ctx->dnco_overflow = nullptr;
     ctx->plan_cap = 0;
 }
 
@@ -406,7 +408,10 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
         GC_HIP(hipMalloc((void **)&ctx->dunit2[i], sizeof(GcTrkUnit) * units));
         GC_HIP(hipMalloc((void **)&ctx->dnsamp2[i], sizeof(int) * units));
         GC_HIP(hipMalloc((void **)&ctx->drounds2[i], sizeof(GcRound) * units * ctx->nseg * GC_MAXR));
+        GC_HIP(hipMalloc((void **)&ctx->dsegs2[i], sizeof(GcUnitSegs) * units));
     }
+    GC_HIP(hipMalloc((void **)&ctx->dnco_overflow, sizeof(int)));
+    GC_HIP(hipMemsetAsync(ctx->dnco_overflow, 0, sizeof(int), ctx->stream));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -434,8 +439,8 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         }
         {
             GcTimed t(ctx, "trk_expand", ps);
-            int r2 = gc_launch_trk_expand(ps, ctx->dchan, ctx->dplan2[s], ctx->dunit2[s], ctx->dnsamp2[s], ctx->nch, nepoch,
-                                          ctx->drounds2[s], ctx->nseg, ctx->max_n);
+            int r2 = gc_launch_trk_expand(ps, ctx->dchan, ctx->dplan2[s], ctx->dunit2[s], ctx->dsegs2[s], ctx->dnsamp2[s],
+                                          ctx->nch, nepoch, ctx->drounds2[s], ctx->nseg, ctx->max_n, ctx->dnco_overflow);
             if (r2) return r2;
         }
         if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[s], ps));
@@ -463,7 +468,7 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
-        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->drounds2[slot], ctx->dpartial2[slot],
+        rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->dsegs2[slot], ctx->drounds2[slot], ctx->dpartial2[slot],
                                 ctx->nch, nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
         if (rc) return rc;
     }
@@ -498,6 +503,19 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     return GNSSCORR_OK;
 }
 
+// Units whose NCO piece tables overflowed (a code step that wraps the code more than ~twice per call, a
+// carrier that visits more than GC_NCAR binades) were not correlated: say so instead of handing out zeros.
+static int nco_check(gnsscorr_ctx *ctx)
+{
+    int n = 0;
+    GC_HIP(hipMemcpy(&n, ctx->dnco_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    if (!n) return GNSSCORR_OK;
+    GC_HIP(hipMemset(ctx->dnco_overflow, 0, sizeof(int)));
+    return gc_fail(GNSSCORR_EINVAL, "tracking: %d (channel, period) units need more NCO pieces than the tables hold "
+                   "(more than two code periods per call, or a carrier crossing more than %d binades); their sums are zero",
+                   n, GC_NCAR);
+}
+
 // trk.II <- correlator's QQ (sum dataQ*code), trk.QQ <- its II: ref src/sdrtrk.c:42
 extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQQ, int *nsamp_out)
 {
@@ -512,7 +530,7 @@ extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQ
     if (nsamp_out)
         GC_HIP(hipMemcpyAsync(nsamp_out, ctx->dnsamp2[ctx->last_slot], sizeof(int) * units, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
-    return GNSSCORR_OK;
+    return nco_check(ctx);
 }
 
 extern "C" int gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ)

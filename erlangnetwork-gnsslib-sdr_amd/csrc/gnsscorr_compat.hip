@@ -22,6 +22,8 @@ struct GcOnce {
     GcChan *chan = nullptr;
     GcTrkPlan *plan = nullptr;
     GcTrkUnit *unit = nullptr;
+    GcUnitSegs *segs = nullptr;
+    int *overflow = nullptr;
     double *out = nullptr;                           // 4*GNSSCORR_MAXTAPS: corrI, corrQ, sumI, sumQ
     int *partial = nullptr;  int partial_cap = 0;    // nseg*2*ntap
     GcRound *rounds = nullptr;  int rounds_cap = 0;  // nseg*GC_MAXR
@@ -37,31 +39,24 @@ static int once_init(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&g_once.chan, sizeof(GcChan)));
     GC_HIP(hipMalloc((void **)&g_once.plan, sizeof(GcTrkPlan)));
     GC_HIP(hipMalloc((void **)&g_once.unit, sizeof(GcTrkUnit)));
+    GC_HIP(hipMalloc((void **)&g_once.segs, sizeof(GcUnitSegs)));
+    GC_HIP(hipMalloc((void **)&g_once.overflow, sizeof(int)));
+    GC_HIP(hipMemsetAsync(g_once.overflow, 0, sizeof(int), ctx->stream));
     GC_HIP(hipMalloc((void **)&g_once.out, sizeof(double) * 4 * GNSSCORR_MAXTAPS));
     GC_HIP(hipMalloc((void **)&g_once.finish, sizeof(unsigned long long) * GC_FINISH_SCRATCH));
     GC_HIP(hipMemsetAsync(g_once.finish, 0, sizeof(unsigned long long) * GC_FINISH_SCRATCH, ctx->stream));
     return 0;
 }
 
-// closed-form NCO remainders on the host; same operations as the device
-// planner (gnsscorr_trk.hip) -- contraction off so that mul/add stay separate
-#pragma clang fp contract(off)
+// NCO remainders returned by the reference (ref src/sdrcmn.c:620,666-668): its running sums walked
+// piece by piece on the host -- the same code as the device planner (gnsscorr_nco.h)
 static void host_rems(double phi0, double freq, double ti, int n, double coff, int smax, double ci,
                       int len, double *remc, double *remp)
 {
-    const double phis = phi0 * GC_CDIV / GC_DPI;
-    const double ps = freq * GC_CDIV * ti;
-    double prem = std::fma((double)n, ps, phis) * GC_DPI / GC_CDIV;
-    if (prem > GC_DPI) prem = std::fma(-std::floor(prem / GC_DPI), GC_DPI, prem);
-    *remp = prem;
-
-    double cs = coff - smax * ci;
-    cs -= std::floor(cs / len) * len;
-    const int nt = n + 2 * smax;
-    double wraps = 0.0;
-    if (nt > 0) wraps = (double)((long long)std::fma((double)(nt - 1), ci, cs) / len);
-    const double cend = std::fma((double)nt, ci, cs) - wraps * len;
-    *remc = cend - smax * ci;
+    GcNoEmit ne;
+    *remp = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, ne));
+    if (ci > 0.0 && ci < (double)len)
+        *remc = gc_code_rem(gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, n + 2 * smax, ne), smax, ci);
 }
 
 // One (channel, period) unit on samples that already sit in a device ring.
@@ -102,18 +97,26 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
         GC_HIP(hipMalloc((void **)&g_once.rounds, sizeof(GcRound) * nseg * GC_MAXR));
         g_once.rounds_cap = nseg;
     }
-    rc = gc_launch_trk_expand(ctx->stream, g_once.chan, g_once.plan, g_once.unit, nullptr, 1, 1, g_once.rounds, nseg, n);
+    rc = gc_launch_trk_expand(ctx->stream, g_once.chan, g_once.plan, g_once.unit, g_once.segs, nullptr, 1, 1, g_once.rounds,
+                              nseg, n, g_once.overflow);
     if (rc) return rc;
-    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.rounds, g_once.partial, 1, 1, nseg, c.ntap, dtype,
-                            c.ntap, n, c.smax);
+    rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.segs, g_once.rounds, g_once.partial, 1, 1, nseg,
+                            c.ntap, dtype, c.ntap, n, c.smax);
     if (rc) return rc;
     rc = gc_launch_trk_finish(ctx->stream, g_once.partial, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
                               g_once.out + 2 * GNSSCORR_MAXTAPS, g_once.out + 3 * GNSSCORR_MAXTAPS, g_once.finish, 1, 1, nseg,
                               c.ntap);
     if (rc) return rc;
     double host[2 * GNSSCORR_MAXTAPS];
+    int over = 0;
     GC_HIP(hipMemcpyAsync(host, g_once.out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipMemcpyAsync(&over, g_once.overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (over) {
+        GC_HIP(hipMemsetAsync(g_once.overflow, 0, sizeof(int), ctx->stream));
+        return gc_fail(GNSSCORR_EINVAL, "correlator: the call spans more code periods (chip step %g x %d samples over %d chips) "
+                       "or carrier binades than the NCO tables hold", ti * crate, n, coden);
+    }
     memcpy(cI, host, sizeof(double) * c.ntap);
     memcpy(cQ, host + GNSSCORR_MAXTAPS, sizeof(double) * c.ntap);
     return 0;

@@ -63,6 +63,8 @@ struct gnsscorr_ctx {
     // per-unit constants, one set per plan slot: the planner stream expands batch k+1 while batch k is correlated
     GcTrkUnit *dunit2[2] = {nullptr, nullptr};
     GcRound *drounds2[2] = {nullptr, nullptr};     // [unit][nseg][GC_MAXR]
+    GcUnitSegs *dsegs2[2] = {nullptr, nullptr};    // [unit]: the unit's carrier / code NCO piece tables
+    int *dnco_overflow = nullptr;                  // units whose NCO tables overflowed since the last fetch
     int *dnsamp2[2] = {nullptr, nullptr};
     int last_slot = 0;                             // slot of the last completed trk_run
     size_t plan_cap = 0;

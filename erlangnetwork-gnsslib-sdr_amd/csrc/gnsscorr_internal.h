@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/gnsscorr.h"
+#include "gnsscorr_nco.h"
 
 #define GC_DPI      (2.0*3.1415926535897932)  // DPI with the reference's PI literal (ref src/sdr.h:103-104)
 #define GC_CDIV     32
@@ -81,42 +82,24 @@ struct GcTrkPlan {
 // Per-unit constants derived from the plan entry (one per channel and epoch).
 struct GcTrkUnit {
     uint64_t a_al;      // 16-byte aligned ring byte offset of the period's first sample group
-    double   cs, ci;    // replica start phase (chips, in [0,len)) and chip step per sample
-    uint64_t phi_fx;    // carrier phase at sample 0, 2^64 = one LUT revolution (32 steps)
-    uint64_t ps_fx;     // carrier step per sample, same scale (two's complement)
     int      head;      // bytes between a_al and the first sample
-    int      n;         // currnsamp
+    int      n;         // currnsamp; 0 = nothing to correlate (outside the reference's scratch, an
+                        // undefined chip step, or an NCO table that overflowed -- counted in nco_overflow)
     int      G;         // 16-byte groups covering the period
     int      nt;        // replica length n + 2*smax
-    int      kflip;     // first sample at which the phase has the sign of the step
-    int      neg;       // bit 0: phase negative before kflip, bit 1: from kflip on
-    double   inv_ci;    // 1/ci: first estimate of a chip's start sample (corrected against T itself)
+    int      ncar;      // pieces of the carrier table
+    int      ncode;     // pieces of the code table
 };
 
-// Fixed-point carrier NCO shared by the tracking and acquisition kernels (and
-// restated by the CPU checker): index = trunc_toward_zero(phase) & 31 in exact
-// arithmetic, 59 fractional bits per LUT step (ref src/sdrcmn.c:649-661).
-#define GC_FX_BIAS ((1ULL << 59) - 1)
-__host__ __device__ inline void gc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0,
-                                              uint64_t *PS, int *kflip, int *neg)
-{
-    const double phis = phi0 * GC_CDIV / GC_DPI;          // exact operations only below this line
-    const double ps = freq * GC_CDIV * ti;
-    const double am = fmod(phis, 32.0);
-    const uint64_t a = (uint64_t)ldexp(fabs(am), 59);
-    const long long p = llrint(ldexp(ps, 59));
-    const uint64_t pm = (uint64_t)(p < 0 ? -p : p);
-    int n0 = am < 0, n1 = p < 0;
-    *A0 = am < 0 ? (uint64_t)0 - a : a;
-    *PS = (uint64_t)p;
-    if (a == 0) n0 = n1;
-    if (pm == 0 || n0 == n1) { *kflip = 0x7fffffff; n1 = n0; }
-    else {
-        const uint64_t kf = a / pm + (a % pm != 0);
-        *kflip = kf > 0x7fffffffULL ? 0x7fffffff : (int)kf;
-    }
-    *neg = n0 | (n1 << 1);
-}
+// The unit's two NCOs as piecewise-linear tables (gnsscorr_nco.h): every LUT index and every chip
+// the kernels derive from them equals what the reference's sample-by-sample fp64 sums give.
+#define GC_NCAR  40     // carrier pieces per code period (one per binade visited: <= ~37 for any phase / frequency below Nyquist)
+#define GC_NCODE 24     // code pieces per call (<= ~2.5 code periods: sdrtracking() asks for one)
+struct GcUnitSegs {
+    int       carK0[GC_NCAR];      // first sample of carrier piece i
+    GcCarSeg  car[GC_NCAR];
+    GcCodeSeg code[GC_NCODE];
+};
 
 // Row statistics of the accumulated power after one acquisition iteration.
 struct GcAcqRow {
@@ -139,14 +122,20 @@ int gc_fail(int code, const char *fmt, ...);
 // One round of the prefix-sum correlator (gnsscorr_trk.hip): the chip edges [q0, q1) its samples can
 // touch, in the numbering period * nedge + list index, and the value of its last chip.
 #define GC_MAXR 16
-struct GcRound { int q0, q1, clast, w0; };     // w0: whole code periods in front of edge q0
+struct GcRound {
+    int q0, q1;         // edges [q0, q1)
+    short clast, w0;    // value of the round's last chip; whole code periods in front of edge q0
+    int hint;           // code piece that holds the round's first replica position
+};
 
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch);
-int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
-                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n);
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch,
+// nco_overflow: device counter of units whose NCO tables did not fit (their outputs are zero)
+int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit, GcUnitSegs *segs,
+                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n, int *nco_overflow);
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs,
+                       const GcRound *rounds, int *partial, int nch,
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max);
 // scratch: GC_FINISH_SCRATCH 64-bit words per channel, zero before the first launch (the kernel leaves them zero)
 #define GC_FINISH_SCRATCH (2 * GNSSCORR_MAXTAPS + 1)

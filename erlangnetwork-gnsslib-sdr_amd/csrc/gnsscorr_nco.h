@@ -122,7 +122,7 @@ GC_HD double gc_carrier_ps(double freq, double ti)
 // Walks n samples from x (= phis); emit(k0, x0, d, count) is called once per piece:
 // samples k0 .. k0+count-1 hold x0 + i d.  Returns the value after n additions.
 template <class Emit>
-GC_HD double gc_carrier_walk(double x, double ps, int n, Emit emit)
+GC_HD double gc_carrier_walk(double x, double ps, int n, Emit &emit)
 {
     GC_FP_STRICT
     int k = 0;
@@ -183,7 +183,7 @@ GC_HD double gc_code_start(double coff, int smax, double ci, int len)
 // truncates to a chip index, already wrapped), w = wraps so far.  Returns the
 // value after nt additions (the reference returns that minus smax*ci, :620).
 template <class Emit>
-GC_HD double gc_code_walk(double c, double ci, int len, int nt, Emit emit)
+GC_HD double gc_code_walk(double c, double ci, int len, int nt, Emit &emit)
 {
     GC_FP_STRICT
     const double dlen = (double)len;
@@ -303,7 +303,7 @@ struct GcCodeTable {
 
 // chip index (before the modulo by the code length is needed: always < len) of replica
 // position j, and the wrap count in front of it
-GC_HD int gc_code_chip_at(const GcCodeSeg *seg, int nseg, int j, int *w)
+GC_HD int gc_code_chip_at(const GcCodeSeg *seg, int nseg, int j, int *w, int *piece = nullptr)
 {
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {                            // last piece with j0 <= j
@@ -312,6 +312,7 @@ GC_HD int gc_code_chip_at(const GcCodeSeg *seg, int nseg, int j, int *w)
     }
     const GcCodeSeg &s = seg[lo];
     if (w) *w = s.w;
+    if (piece) *piece = lo;
     int i = j - s.j0;
     if (i < 0) i = 0;
     if (i >= s.cnt) i = s.cnt - 1;

@@ -86,16 +86,43 @@ __global__ void power_kernel(const float2 *__restrict__ a, double *__restrict__ 
     conv[i] = flagsum ? conv[i] + v : v;
 }
 
-// ref src/sdrcmn.c:633-669 (samples), closed-form phase; optional float2 output
-// scaled as cpxcpx() does (ref src/sdrcmn.c:185-195)
-__global__ void mix_kernel(const int8_t *__restrict__ data, int dtype, int n, uint64_t A0, uint64_t PS,
-                           int kflip, int neg, short *__restrict__ I, short *__restrict__ Q,
+// NCO piece tables of one mixcarr() / rescode() call (gnsscorr_nco.h), built by one device thread
+#define GC_OPSEG 256
+struct GcOpTables {
+    int ncar, ncode, overflow, pad;
+    int k0[GC_OPSEG];
+    GcCarSeg car[GC_OPSEG];
+    GcCodeSeg code[GC_OPSEG];
+};
+
+__global__ void op_tables_kernel(GcOpTables *__restrict__ t, int n, double phi0, double freq, double ti,
+                                 int nt, double coff, int smax, double ci, int len)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    t->ncar = t->ncode = t->overflow = 0;
+    if (n > 0) {
+        GcCarTable ct{t->k0, t->car, GC_OPSEG, 0, 0};
+        gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, ct);
+        t->ncar = ct.n;
+        t->overflow |= ct.overflow;
+    }
+    if (nt > 0) {
+        GcCodeTable dt{t->code, GC_OPSEG, 0, 0};
+        gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, nt, dt);
+        t->ncode = dt.n;
+        t->overflow |= dt.overflow;
+    }
+}
+
+// ref src/sdrcmn.c:633-669 (samples); optional float2 output scaled as cpxcpx() does (ref
+// src/sdrcmn.c:185-195)
+__global__ void mix_kernel(const int8_t *__restrict__ data, int dtype, int n, const GcOpTables *__restrict__ t,
+                           short *__restrict__ I, short *__restrict__ Q,
                            float2 *__restrict__ cpx, float scale)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const bool ng = k < kflip ? (neg & 1) : (neg >> 1);
-    const int idx = (int)((A0 + (uint64_t)k * PS + (ng ? GC_FX_BIAS : 0ULL)) >> 59);
+    const int idx = gc_carrier_idx_at(t->k0, t->car, t->ncar, k);
     const int c = oCos32[idx], s = oSin32[idx];
     int vi, vq;
     if (dtype == 2) {
@@ -112,14 +139,13 @@ __global__ void mix_kernel(const int8_t *__restrict__ data, int dtype, int n, ui
     if (cpx) cpx[k] = make_float2((float)vi * scale, (float)vq * scale);
 }
 
-// ref src/sdrcmn.c:608-621, closed-form code phase
-__global__ void rescode_kernel(const short *__restrict__ code, int len, double cs, double ci, int nt,
+// ref src/sdrcmn.c:608-621
+__global__ void rescode_kernel(const short *__restrict__ code, const GcOpTables *__restrict__ t, int nt,
                                short *__restrict__ rcode)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nt) return;
-    const long long t = (long long)__fma_rn((double)j, ci, cs);
-    rcode[j] = code[(int)(t % len)];
+    rcode[j] = code[gc_code_chip_at(t->code, t->ncode, j, nullptr)];
 }
 
 __global__ void cpxcpx_kernel(const short *__restrict__ I, const short *__restrict__ Q, float scale, int n,
@@ -214,13 +240,25 @@ struct Guard {             // default context + lock + device, or a printed erro
     explicit operator bool() const { return ctx != nullptr; }
 };
 
-#pragma clang fp contract(off)
-double host_prem(double phi0, double freq, double ti, int n)
+GcOpTables *g_optab = nullptr;
+
+// builds the call's tables on the device; returns nonzero (and prints) when they do not fit
+int op_tables(gnsscorr_ctx *ctx, const char *who, int n, double phi0, double freq, double ti, int nt, double coff,
+              int smax, double ci, int len)
 {
-    const double phis = phi0 * GC_CDIV / GC_DPI, ps = freq * GC_CDIV * ti;
-    double prem = std::fma((double)n, ps, phis) * GC_DPI / GC_CDIV;
-    if (prem > GC_DPI) prem = std::fma(-std::floor(prem / GC_DPI), GC_DPI, prem);
-    return prem;
+    if (!g_optab && hipMalloc((void **)&g_optab, sizeof(GcOpTables)) != hipSuccess) {
+        SDRPRINTF("error: %s memory allocation\n", who);
+        return -1;
+    }
+    hipLaunchKernelGGL(op_tables_kernel, dim3(1), dim3(1), 0, ctx->stream, g_optab, n, phi0, freq, ti, nt, coff, smax, ci, len);
+    int over = 0;
+    if (hipMemcpyAsync(&over, &g_optab->overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        SDRPRINTF("error: %s: HIP failure\n", who);
+        return -1;
+    }
+    if (over) SDRPRINTF("error: %s: the call needs more than %d NCO pieces (code periods / carrier binades per call)\n", who, GC_OPSEG);
+    return over;
 }
 
 }  // namespace
@@ -326,19 +364,17 @@ double mixcarr(const char *data, int dtype, double ti, int n, double freq, doubl
     if (!d || !dI || !dQ) { SDRPRINTF("error: mixcarr memory allocation\n"); return 0.0; }
     hipStream_t st = g.ctx->stream;
     hipMemcpyAsync(d, data, (size_t)n * dtype, hipMemcpyHostToDevice, st);
-    uint64_t A0, PS;
-    int kflip, neg;
-    gc_carrier_fx(phi0, freq, ti, &A0, &PS, &kflip, &neg);
-    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, dtype, n, A0, PS, kflip, neg, dI, dQ,
+    if (op_tables(g.ctx, "mixcarr", n, phi0, freq, ti, 0, 0.0, 0, 0.0, 1)) return 0.0;
+    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, dtype, n, g_optab, dI, dQ,
                        (float2 *)nullptr, 0.0f);
     hipMemcpyAsync(II, dI, sizeof(short) * n, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(QQ, dQ, sizeof(short) * n, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) SDRPRINTF("error: mixcarr: HIP failure\n");
-    return host_prem(phi0, freq, ti, n);
+    GcNoEmit ne;
+    return gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, ne));
 }
 
 // ref src/sdrcmn.c:608-621
-#pragma clang fp contract(off)
 double rescode(const short *code, int len, double coff, int smax, double ci, int n, short *rcode)
 {
     Guard g("rescode");
@@ -348,14 +384,13 @@ double rescode(const short *code, int len, double coff, int smax, double ci, int
     if (!dc || !dr) { SDRPRINTF("error: rescode memory allocation\n"); return 0.0; }
     hipStream_t st = g.ctx->stream;
     hipMemcpyAsync(dc, code, sizeof(short) * len, hipMemcpyHostToDevice, st);
-    double cs = coff - smax * ci;
-    cs -= std::floor(cs / len) * len;
-    hipLaunchKernelGGL(rescode_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, dc, len, cs, ci, nt, dr);
+    if (!(ci > 0.0 && ci < (double)len)) { SDRPRINTF("error: rescode: chip step %g outside (0, %d)\n", ci, len); return 0.0; }
+    if (op_tables(g.ctx, "rescode", 0, 0.0, 0.0, 0.0, nt, coff, smax, ci, len)) return 0.0;
+    hipLaunchKernelGGL(rescode_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, dc, g_optab, nt, dr);
     hipMemcpyAsync(rcode, dr, sizeof(short) * nt, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) SDRPRINTF("error: rescode: HIP failure\n");
-    const double wraps = (double)((long long)std::fma((double)(nt - 1), ci, cs) / len);
-    const double cend = std::fma((double)nt, ci, cs) - wraps * len;
-    return cend - smax * ci;
+    GcNoEmit ne;
+    return gc_code_rem(gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, nt, ne), smax, ci);
 }
 
 // ref src/sdrcmn.c:738-773 with the reference's own m-point transforms
@@ -381,10 +416,8 @@ void pcorrelator(const char *data, int dtype, double ti, int n, double *freq, in
     hipMemcpyAsync(dP, P, sizeof(double) * (size_t)n * nfreq, hipMemcpyHostToDevice, st);
     const float sc = (float)(CSCALE / m);
     for (int i = 0; i < nfreq; i++) {
-        uint64_t A0, PS;
-        int kflip, neg;
-        gc_carrier_fx(0.0, freq[i], ti, &A0, &PS, &kflip, &neg);
-        hipLaunchKernelGGL(mix_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d, dtype, m, A0, PS, kflip, neg,
+        if (op_tables(g.ctx, "pcorrelator", m, 0.0, freq[i], ti, 0, 0.0, 0, 0.0, 1)) return;
+        hipLaunchKernelGGL(mix_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d, dtype, m, g_optab,
                            (short *)nullptr, (short *)nullptr, x, sc);
         if (conv_dev(g.ctx, x, t, cx, m, n, 1, dP + (size_t)i * n)) {
             SDRPRINTF("error: pcorrelator: %s\n", gnsscorr_last_error());

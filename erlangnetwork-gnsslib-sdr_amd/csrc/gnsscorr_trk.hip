@@ -26,123 +26,46 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// closed-form NCO chain (the test-side CPU checker restates these operations
-// one for one; any change here changes the normative closed form)
+// NCO chain of sdrtracking() (ref src/sdrtrk.c:31-43): the reference's running
+// fp64 sums walked piece by piece (gnsscorr_nco.h), bit for bit
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double gc_carrier_rem(double phi0, double freq, double ti, int n)
+// one channel per wavefront (lane 0 works): the chain of a channel is sequential in its periods,
+// the channels run side by side on different compute units
+__global__ __launch_bounds__(64) void trk_plan_kernel(const GcChan *__restrict__ chan,
+                                                      const GcTrkState *__restrict__ state_in,
+                                                      GcTrkState *__restrict__ state_out,
+                                                      GcTrkPlan *__restrict__ plan, int nch, int nepoch)
 {
-    const double phis = __ddiv_rn(__dmul_rn(phi0, (double)GC_CDIV), GC_DPI);
-    const double ps = __dmul_rn(__dmul_rn(freq, (double)GC_CDIV), ti);
-    double prem = __ddiv_rn(__dmul_rn(__fma_rn((double)n, ps, phis), GC_DPI), (double)GC_CDIV);
-    if (prem > GC_DPI) prem = __fma_rn(-floor(__ddiv_rn(prem, GC_DPI)), GC_DPI, prem);
-    return prem;
-}
-
-// start offset of the resampled replica: coff - smax*ci reduced to [0,len)
-__device__ __forceinline__ double gc_code_start(double coff, int smax, double ci, int len)
-{
-    double cs = __dsub_rn(coff, __dmul_rn((double)smax, ci));
-    cs = __dsub_rn(cs, __dmul_rn(floor(__ddiv_rn(cs, (double)len)), (double)len));
-    return cs;
-}
-
-__device__ __forceinline__ double gc_code_rem(double coff, int smax, double ci, int len, int n)
-{
-    const double cs = gc_code_start(coff, smax, ci, len);
-    const int nt = n + 2 * smax;
-    double wraps = 0.0;
-    if (nt > 0) wraps = (double)((long long)__fma_rn((double)(nt - 1), ci, cs) / len);
-    const double cend = __dsub_rn(__fma_rn((double)nt, ci, cs), __dmul_rn(wraps, (double)len));
-    return __dsub_rn(cend, __dmul_rn((double)smax, ci));
-}
-
-// x / b with y = RN(1/b) given: q = RN(x y), r = x - b q (exact by fma), RN(q + r y) is the correctly
-// rounded quotient (Markstein's theorem) -- three dependent operations instead of the ten of the
-// hardware division sequence.  The planner is one sequential chain per channel; its divisions are
-// the critical path of the whole tracking step.  (Checked against true division: 2.5e8 random
-// operands for b = 2 pi and for chip-per-sample ratios, no mismatch.)
-__device__ __forceinline__ double gc_div_y(double x, double b, double y)
-{
-    const double q = __dmul_rn(x, y);
-    const double r = __fma_rn(-q, b, x);
-    return __fma_rn(r, y, q);
-}
-
-// gc_carrier_rem / gc_code_rem with the loop invariants hoisted and the divisions by constants
-// replaced by their exact equivalents: same values, bit for bit
-__device__ __forceinline__ double plan_carrier_rem(double phi0, double ps, int n, double ydpi)
-{
-    const double phis = gc_div_y(__dmul_rn(phi0, (double)GC_CDIV), GC_DPI, ydpi);
-    // / GC_CDIV (a power of two) is an exact scaling
-    const double prem = __dmul_rn(__dmul_rn(__fma_rn((double)n, ps, phis), GC_DPI), 1.0 / (double)GC_CDIV);
-    const double wrapped = __fma_rn(-floor(gc_div_y(prem, GC_DPI, ydpi)), GC_DPI, prem);
-    return prem > GC_DPI ? wrapped : prem;
-}
-
-__device__ __forceinline__ double plan_code_rem(double coff, double smaxci, double ci, double dlen, double ylen, int nt)
-{
-    double cs = __dsub_rn(coff, smaxci);
-    // floor(cs / len): cs / len rounds to a value with the same floor as the exact quotient while
-    // -len <= cs < len (the neighbours of -1, 0 and 1 are more than an ulp away from cs / len)
-    double fl = cs < 0.0 ? -1.0 : 0.0;
-    if (!(cs >= -dlen && cs < dlen)) fl = floor(__ddiv_rn(cs, dlen));
-    cs = __dsub_rn(cs, __dmul_rn(fl, dlen));
-    const double x = __fma_rn((double)(nt - 1), ci, cs);
-    const double T = trunc(x);
-    // integer quotient T div len in fp64: estimate by the reciprocal, settle by exact products
-    double q = floor(__dmul_rn(T, ylen));
-    const bool up = __fma_rn(q + 1.0, dlen, -T) <= 0.0, down = __fma_rn(q, dlen, -T) > 0.0;
-    q = up ? q + 1.0 : (down ? q - 1.0 : q);
-    if (!(T >= 0.0 && T < 2147483648.0)) q = (double)((long long)x / (long long)dlen);
-    const double wraps = nt > 0 ? q : 0.0;
-    const double cend = __dsub_rn(__fma_rn((double)nt, ci, cs), __dmul_rn(wraps, dlen));
-    return __dsub_rn(cend, smaxci);
-}
-
-__global__ void trk_plan_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
-                                GcTrkState *__restrict__ state_out, GcTrkPlan *__restrict__ plan, int nch,
-                                int nepoch)
-{
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= nch) return;
+    const int ch = blockIdx.x;
+    if (ch >= nch || threadIdx.x != 0) return;
     const GcChan c = chan[ch];
     GcTrkState s = state_in[ch];
-    const double ci = __dmul_rn(c.ti, s.codefreq);
-    const double spc = __ddiv_rn(s.codefreq, c.f_sf);      // chips per sample
-    // loop invariants of the closed forms (frequencies are held over the batch)
-    const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_DPI);
-    const double dlen = (double)c.clen, ylen = __ddiv_rn(1.0, dlen);
-    const double ps = __dmul_rn(__dmul_rn(s.carrfreq, (double)GC_CDIV), c.ti);
-    const double smaxci = __dmul_rn((double)c.smax, ci);
+    const double ci = __dmul_rn(c.ti, s.codefreq);          // ti*crate, ref src/sdrcmn.c:709
+    const double spc = __ddiv_rn(s.codefreq, c.f_sf);       // chips per sample
+    const double ps = gc_carrier_ps(s.carrfreq, c.ti);
+    const double dlen = (double)c.clen;
+    const bool code_ok = ci > 0.0 && ci < dlen;             // the reference's one-subtraction wrap (:617) needs it
     GcTrkPlan p;
     p.carrfreq = s.carrfreq;
     p.codefreq = s.codefreq;
     p.pad = 0;
     GcTrkPlan *out = plan + (size_t)ch * nepoch;
-    if (spc > 0.0 && spc < 1e300 && yspc < 1e300) {
-        for (int e = 0; e < nepoch; e++) {
-            const int n = (int)gc_div_y(__dsub_rn(dlen, s.remcode), spc, yspc);    // ref src/sdrtrk.c:31-32
-            p.buffloc = s.buffloc;
-            p.coff = s.remcode;
-            p.phi0 = s.remcarr;
-            p.n = n;
-            out[e] = p;
-            s.remcarr = plan_carrier_rem(s.remcarr, ps, n, ydpi);
-            s.remcode = plan_code_rem(s.remcode, smaxci, ci, dlen, ylen, n + 2 * c.smax);
-            s.buffloc += (uint64_t)(int64_t)n;
+    GcNoEmit ne;
+    for (int e = 0; e < nepoch; e++) {
+        const double q = __ddiv_rn(__dsub_rn(dlen, s.remcode), spc);        // ref src/sdrtrk.c:31-32
+        const int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
+        p.buffloc = s.buffloc;
+        p.coff = s.remcode;
+        p.phi0 = s.remcarr;
+        p.n = n;
+        out[e] = p;
+        if (n > 0 && n <= (1 << 24)) {
+            s.remcarr = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(s.remcarr), ps, n, ne));
+            if (code_ok)
+                s.remcode = gc_code_rem(gc_code_walk(gc_code_start(s.remcode, c.smax, ci, c.clen), ci, c.clen,
+                                                     n + 2 * c.smax, ne), c.smax, ci);
         }
-    } else {                    // degenerate rates: the literal operations
-        for (int e = 0; e < nepoch; e++) {
-            const int n = (int)__ddiv_rn(__dsub_rn(dlen, s.remcode), spc);
-            p.buffloc = s.buffloc;
-            p.coff = s.remcode;
-            p.phi0 = s.remcarr;
-            p.n = n;
-            out[e] = p;
-            s.remcarr = gc_carrier_rem(s.remcarr, s.carrfreq, c.ti, n);
-            s.remcode = gc_code_rem(s.remcode, c.smax, ci, c.clen, n);
-            s.buffloc += (uint64_t)(int64_t)n;
-        }
+        s.buffloc += (uint64_t)(int64_t)n;
     }
     state_out[ch] = s;
 }
@@ -160,18 +83,21 @@ __host__ __device__ inline int trk_ps_rounds(int dtype, int max_n, int nit)
 __host__ __device__ inline int trk_ps_nit(int dtype, int nit) { return dtype == 1 ? 1 : nit; }
 
 // ---------------------------------------------------------------------------
-// per-unit constants
+// per-unit constants and NCO tables
 // ---------------------------------------------------------------------------
-// One lane per (channel, epoch): everything the correlator workgroups would
-// otherwise each recompute (ring offset, NCO start values).
+// One lane per (channel, epoch): ring offset, the two NCOs of the period as piece tables, and per
+// round of the correlator the chip edges its samples can touch.
 __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
-                                  GcTrkUnit *__restrict__ unit, int *__restrict__ nsamp_out, int nch,
-                                  int nepoch, GcRound *__restrict__ rounds, int nseg, int max_n, int nit)
+                                  GcTrkUnit *__restrict__ unit, GcUnitSegs *__restrict__ segs,
+                                  int *__restrict__ nsamp_out, int nch, int nepoch,
+                                  GcRound *__restrict__ rounds, int nseg, int max_n, int nit,
+                                  int *__restrict__ nco_overflow)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nch * nepoch) return;
     const GcChan &c = chan[i / nepoch];
     const GcTrkPlan p = plan[i];
+    GcUnitSegs *sg = segs + i;
     GcTrkUnit u;
     const uint64_t a0 = (p.buffloc % c.ringlen) * (uint64_t)c.dtype;
     u.a_al = a0 & ~(uint64_t)15;
@@ -179,17 +105,35 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     u.n = p.n;
     u.G = (u.head + p.n * c.dtype + 15) >> 4;
     u.nt = p.n + 2 * c.smax;
-    u.ci = __dmul_rn(c.ti, p.codefreq);
-    u.cs = gc_code_start(p.coff, c.smax, u.ci, c.clen);
-    gc_carrier_fx(p.phi0, p.carrfreq, c.ti, &u.phi_fx, &u.ps_fx, &u.kflip, &u.neg);
-    u.inv_ci = 1.0 / u.ci;
-    unit[i] = u;
+    u.ncar = 0;
+    u.ncode = 0;
     if (nsamp_out) nsamp_out[i] = p.n;
+    const double ci = __dmul_rn(c.ti, p.codefreq);
+    // outside the reference's (nsamp+100) scratch (ref src/sdrtrk.c:23), or a chip step for which its
+    // one-subtraction code wrap (src/sdrcmn.c:617) is undefined: nothing is correlated
+    if (!(p.n > 0 && p.n <= max_n && ci > 0.0 && ci < (double)c.clen)) {
+        u.n = 0;
+        unit[i] = u;
+        return;
+    }
+    GcCarTable ct{sg->carK0, sg->car, GC_NCAR, 0, 0};
+    gc_carrier_walk(gc_carrier_phis(p.phi0), gc_carrier_ps(p.carrfreq, c.ti), p.n, ct);
+    GcCodeTable dt{sg->code, GC_NCODE, 0, 0};
+    gc_code_walk(gc_code_start(p.coff, c.smax, ci, c.clen), ci, c.clen, u.nt, dt);
+    u.ncar = ct.n;
+    u.ncode = dt.n;
+    if (ct.overflow || dt.overflow) {
+        if (nco_overflow) atomicAdd(nco_overflow, 1);
+        u.n = 0;
+        unit[i] = u;
+        return;
+    }
+    unit[i] = u;
 
     // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel): round r of workgroup
     // seg covers samples [kl, kl + rsamp) of the period and can touch the chips T(first sample) ..
     // T(last sample + 2 smax); rank[] turns those into positions in the code's edge list
-    if (!rounds || !(p.n > 0 && p.n <= max_n && u.ci > 0.0 && u.ci < (double)c.clen)) return;
+    if (!rounds) return;
     const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
     const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
     const unsigned short *rank = (const unsigned short *)(c.code + 1024);
@@ -201,15 +145,15 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
             const int kl = klo + r * rsamp;
             const int kfirst = kl > 0 ? kl : 0;
             const int kend = (kl + rsamp < p.n ? kl + rsamp : p.n);
-            int ma = (int)__fma_rn((double)kfirst, u.ci, u.cs);
-            int mb = (int)__fma_rn((double)(kend - 1 + 2 * c.smax), u.ci, u.cs), wa = 0, wb = 0;
-            wa = ma / c.clen; ma -= wa * c.clen;
-            wb = mb / c.clen; mb -= wb * c.clen;
+            int wa = 0, wb = 0, hint = 0;
+            const int ma = gc_code_chip_at(sg->code, dt.n, kfirst, &wa, &hint);
+            const int mb = gc_code_chip_at(sg->code, dt.n, kend - 1 + 2 * c.smax, &wb, nullptr);
             GcRound ro;
             ro.q0 = wa * c.nedge + (int)rank[ma];
             ro.q1 = wb * c.nedge + (int)rank[mb];
-            ro.clast = (int)c.code[mb];
-            ro.w0 = wa;
+            ro.clast = (short)c.code[mb];
+            ro.w0 = (short)wa;
+            ro.hint = hint;
             rounds[((size_t)i * nseg + seg) * GC_MAXR + r] = ro;
         }
     }
@@ -281,6 +225,7 @@ __device__ __forceinline__ int dot4z(unsigned a, unsigned b)
 template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict__ chan,
                                                        const GcTrkUnit *__restrict__ unit,
+                                                       const GcUnitSegs *__restrict__ segs,
                                                        int *__restrict__ partial, int nch, int nepoch, int nseg,
                                                        int ntap_stride, int ntap_lo, int max_n, int ablate)
 {
@@ -367,16 +312,31 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     }
 
     GC_STAMP(2);
-    // ---- resampled replica, ref src/sdrcmn.c:608-621 in closed form --------------------------
-    // position j of the replica (j = smax + k + tap offset) lives at rcp[j - klo]; chip index
-    // T(j) = trunc(fma(j, ci, cs)) is non-decreasing in j, so a 17-position task needs two
-    // evaluations plus a 4-step bisection when it holds one chip edge.
-    const double ci = u.ci, cs = u.cs;
+    // ---- resampled replica, ref src/sdrcmn.c:608-621 -----------------------------------------
+    // position j of the replica (j = smax + k + tap offset) lives at rcp[j - klo]; the unwrapped chip
+    // index T(j) (the reference's truncated running sum, from the unit's code table) is non-decreasing
+    // in j, so a 17-position task needs two evaluations plus a 4-step bisection when it holds one
+    // chip edge.
     const int nt = u.nt;
     const gc_gptr_i8 code = (gc_gptr_i8)c.code;
     const int npos = SEGS + 2 * smax + 1;           // positions this segment can touch
     constexpr int RS = SEGS / 8 + 64;               // row stride (dwords) of the transposed image
-    auto chipT = [&](int j) -> int { return (int)(long long)__fma_rn((double)j, ci, cs); };
+    // the unit's NCO tables, behind the replica image
+    int *sk0 = reinterpret_cast<int *>(smem + LUT_BYTES + RED_BYTES + 8 * RS * 4);
+    GcCarSeg *scar = reinterpret_cast<GcCarSeg *>(sk0 + ((GC_NCAR + 4) & ~3));
+    GcCodeSeg *scode = reinterpret_cast<GcCodeSeg *>(scar + GC_NCAR);
+    const int ncar = u.ncar, ncode = u.ncode;
+    {
+        const GcUnitSegs *gs = segs + ((size_t)ch * nepoch + e);
+        if (tid < ncar) { sk0[tid] = gs->carK0[tid]; scar[tid] = gs->car[tid]; }
+        if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = gs->code[tid - 64];
+    }
+    __syncthreads();
+    auto chipT = [&](int j) -> int {
+        int w = 0;
+        const int chip = gc_code_chip_at(scode, ncode, j, &w);
+        return chip + w * clen;
+    };
     auto chipS = [&](int T) -> int { while (T >= clen) T -= clen; return (int)code[T]; };
     for (int q = tid; q * 16 < npos && !(ablate & 1); q += 256) {
         const int j0 = klo + q * 16;
@@ -425,11 +385,6 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
     __syncthreads();
     GC_STAMP(4);
 
-    // carrier NCO: the truncation bias of a negative phase is folded into the start value unless
-    // the phase changes sign inside this period (then it is chosen per sample)
-    const bool flip = u.kflip < n;
-    const unsigned long long ps = u.ps_fx;
-    const unsigned long long phi0 = u.phi_fx + ((!flip && (u.neg & 1)) ? GC_FX_BIAS : 0ULL);
     int accI[NTAP], accQ[NTAP], toff[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; t++) {
@@ -438,10 +393,9 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0);
     }
 
-    // the sign-flip variant (a carrier phase that crosses zero inside the period) is a separate copy
-    // of the loop, chosen once per workgroup, so the common copy stays one basic block per group
-    auto run = [&](auto flip_tag) {
-        constexpr bool FLIP = decltype(flip_tag)::value;
+    // (this form looks every sample's LUT index up in the carrier table on its own: it is the
+    // independent cross-check of the production kernel, not a fast path)
+    auto run = [&]() {
     #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int gl = tid + 256 * it, g = g0 + gl;
@@ -466,20 +420,18 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
             }
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
             unsigned ip[SPG / 2], qp[SPG / 2];
-            unsigned long long phi = phi0 + (unsigned long long)(long long)kb * ps;
     #pragma unroll
             for (int i = 0; i < SPG; i += 2) {
                 int I[2], Q[2];
     #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    unsigned long long ph = phi;
-                    if (FLIP) ph += (((kb + i + s2 < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
                     const int pos = DTYPE == 2 ? ((i + s2) & 1) : ((i + s2) & 3);
-                    const uint2 l = lut[32 * pos + (int)(ph >> 59)];
+                    const int kk = kb + i + s2;
+                    const int idx = gc_carrier_idx_at(sk0, scar, ncar, kk < 0 ? 0 : kk);
+                    const uint2 l = lut[32 * pos + idx];
                     const unsigned wd = w[DTYPE == 2 ? (i + s2) >> 1 : (i + s2) >> 2];
                     I[s2] = dot4z(wd, l.x);
                     Q[s2] = dot4z(wd, l.y);
-                    phi += ps;
                 }
                 ip[i >> 1] = __builtin_amdgcn_perm((unsigned)I[1], (unsigned)I[0], 0x05040100u);
                 qp[i >> 1] = __builtin_amdgcn_perm((unsigned)Q[1], (unsigned)Q[0], 0x05040100u);
@@ -498,7 +450,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(const GcChan *__restrict_
         }
 
     };
-    if (flip) run(std::true_type{}); else run(std::false_type{});
+    run();
     GC_STAMP(5);
 
     // wavefront then workgroup reduction
@@ -584,7 +536,11 @@ struct PsLayout {
     static constexpr int WT_OFF = LUT_BYTES;                    // wpre[2][8] int2 (two rounds in flight)
     static constexpr int LB_OFF = WT_OFF + 128;
     static constexpr int LOC_OFF = LB_OFF + ((257 * 8 + 15) & ~15);
-    static constexpr int RED_OFF = LOC_OFF + (((256 * LPAD + 1) * 8 + 15) & ~15);
+    // the unit's NCO tables: carrier piece starts (+ closing sentinel), carrier pieces, code pieces
+    static constexpr int K0_OFF = LOC_OFF + (((256 * LPAD + 1) * 8 + 15) & ~15);
+    static constexpr int CAR_OFF = K0_OFF + (((GC_NCAR + 1) * 4 + 15) & ~15);
+    static constexpr int CODE_OFF = CAR_OFF + GC_NCAR * (int)sizeof(GcCarSeg);
+    static constexpr int RED_OFF = CODE_OFF + GC_NCODE * (int)sizeof(GcCodeSeg);
     static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
 };
 
@@ -602,6 +558,7 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 13 ? 3 : (NTAP <= 21 ? 2 : 1)), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
                                                           const GcTrkUnit *__restrict__ unit,
+                                                          const GcUnitSegs *__restrict__ segs,
                                                           const GcRound *__restrict__ rounds,
                                                           int *__restrict__ partial, int nch, int nepoch, int nseg,
                                                           int ntap_stride, int ntap_lo, int max_n, int rpw,
@@ -634,10 +591,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     const int n = u.n, smax = c.smax, clen = c.clen, head = u.head, G = u.G;
     int *pout = partial + (((size_t)ch * nepoch + e) * nseg + seg) * 2 * ntap_stride;
     const int g0 = seg * RGRP * rpw;
-    const double ci = u.ci, cs = u.cs, inv = u.inv_ci;
-    // outside the reference's (nsamp+100) scratch, nothing left for this workgroup, or a chip step
-    // for which the reference's one-subtraction code wrap (src/sdrcmn.c:617) is undefined
-    if (n <= 0 || n > max_n || g0 >= G || !(ci > 0.0 && ci < (double)clen)) {
+    // nothing to correlate (trk_expand: outside the reference's scratch, undefined chip step, NCO table
+    // overflow) or nothing left for this workgroup
+    if (n <= 0 || n > max_n || g0 >= G) {
         if (tid < 2 * ntap_stride) pout[tid] = 0;
         return;
     }
@@ -652,6 +608,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF);         // [256 + 1]
     int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [256 lanes][LPAD] + closing entry
     int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x 2*NTAP
+    int *sk0 = reinterpret_cast<int *>(smem + L::K0_OFF);             // [ncar] + INT_MAX
+    GcCarSeg *scar = reinterpret_cast<GcCarSeg *>(smem + L::CAR_OFF);
+    GcCodeSeg *scode = reinterpret_cast<GcCodeSeg *>(smem + L::CODE_OFF);
 
     const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
@@ -692,7 +651,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     const gc_gptr_i8 code = (gc_gptr_i8)c.code;
     const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)(code + 3072);
     const int nedge = c.nedge;
-    auto chipT = [&](int j) -> int { return (int)__fma_rn((double)j, ci, cs); };
+    const int ncar = u.ncar, ncode = u.ncode;
+    {
+        const GcUnitSegs *gs = segs + ((size_t)ch * nepoch + e);
+        if (tid < ncar) { sk0[tid] = gs->carK0[tid]; scar[tid] = gs->car[tid]; }
+        if (tid == ncar) sk0[tid] = 0x7fffffff;
+        if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = gs->code[tid - 64];
+    }
     if (tid < 32 * LUTPOS) {
         const int idx = tid & 31, pos = tid >> 5;
         const int cs_ = lut_cos(idx), sn_ = lut_cos((idx - 8) & 31);     // sin(i) = cos(i - 8)
@@ -713,9 +678,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     if (tid < 32) wpre[tid] = 0;
     __syncthreads();
 
-    const bool flip = u.kflip < n;
-    const unsigned long long ps = u.ps_fx;
-    const unsigned long long phi0 = u.phi_fx + ((!flip && (u.neg & 1)) ? GC_FX_BIAS : 0ULL);
     const bool pm1 = c.pm1 != 0;
     unsigned accI[NTAP], accQ[NTAP], finI = 0, finQ = 0;
     int toff[NTAP];
@@ -725,19 +687,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         accQ[t] = 0;
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
     }
-    // carrier phase of this lane's first sample of the round; a round further on it is RSAMP steps later
-    unsigned long long phir = phi0 + (unsigned long long)(long long)(klo + tid * LSP) * ps;
-    const unsigned long long psr = (unsigned long long)RSAMP * ps;
+    int wseg = 0;                                       // wave-uniform: carrier piece of the wave's first sample
     const GcRound *myrounds = rounds + (((size_t)ch * nepoch + e) * nseg + seg) * GC_MAXR;
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
-    auto edge_js = [&](int ed, int w) -> int {          // start sample of the chip the list entry names
-        // B = min{j : T(j) >= m}.  The estimate ceil((m - cs) / ci) is within one sample of it (its
-        // error is ~1e-11 samples for j < 2^15), so B is one of jc-1, jc, jc+1: T decides which.
-        const int m = (int)(short)(ed & 0xFFFF) + w * clen;
-        int jc = (int)ceil(((double)m - cs) * inv);
-        if (jc < 1) jc = 1;
-        const bool below = chipT(jc - 1) >= m, at = chipT(jc) >= m;
-        return below ? jc - 1 : (at ? jc : jc + 1);
+    auto edge_js = [&](int ed, int w, int hint) -> int { // start position of the chip the list entry names
+        // B = min{j : T(j) >= m in code period w}, T = the reference's truncated running sum.  The code
+        // table holds that sum as pieces y0 + i d: the first piece (from the round's first one) whose last
+        // value reaches m holds B, and inside it i = ceil((m - y0)/d), settled by two exact evaluations.
+        const int m = (int)(short)(ed & 0xFFFF);
+        const double thr = m ? (double)m : -0.5;        // chip 0: any value above -1 truncates to it
+        int sp = hint;
+        bool hit = false;
+        while (true) {
+            const int sw = scode[sp].w;
+            hit = sw > w || (sw == w && scode[sp].ylast >= thr);
+            if (hit || sp + 1 >= ncode) break;
+            sp++;
+        }
+        const int j0 = scode[sp].j0;
+        if (!hit) return j0 + scode[sp].cnt;            // past the replica: clamped away by the look-ups
+        const double d = scode[sp].d, y0 = scode[sp].y0;
+        int i = 0;
+        if (scode[sp].w == w && d != 0.0 && thr > y0) {
+            i = (int)ceil((thr - y0) * scode[sp].inv);
+            if (i < 1) i = 1;
+            if (__fma_rn((double)(i - 1), d, y0) >= thr) i--;
+            else if (__fma_rn((double)i, d, y0) < thr) i++;
+        }
+        return j0 + i;
     };
     auto edge_load = [&](int q, int w0, int *w) -> int {  // w0: code periods in front of the round's first edge
         q -= w0 * nedge;
@@ -758,7 +735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         if (r == 1) GC_STAMP(2);
         if (r + 1 < nround) load_round(r + 1, vnext);
         const GcRound ro = myrounds[r];
-        const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0;
+        const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0, rhint = ro.hint;
         int q = rq0 + tl, ew = 0, ed = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
         if (q < q1) ed = edge_load(q, rw0, &ew);       // in flight during the mixing phase
@@ -770,9 +747,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         const int roff = r * RSAMP;
         // only the first and the last round of a period hold samples outside [0, n)
         const bool ragged = kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G;
-        auto run = [&](auto flip_tag) {
-            constexpr bool FLIP = decltype(flip_tag)::value;
-            unsigned long long phi = phir;              // phase of the lane's first sample this round
+        // carrier pieces: the wave's 64 * LSP samples start in piece wseg; when no other piece starts
+        // inside them (the common case -- a piece is a whole binade of the running phase) every lane
+        // steps the same piece, otherwise each lane finds its own and switches where the next one starts
+        const int kw = kl + wv * 64 * LSP;
+        while (sk0[wseg + 1] <= kw) wseg++;
+        const bool onepiece = sk0[wseg + 1] >= kw + 64 * LSP;
+        auto run = [&](auto multi_tag) {
+            constexpr bool MULTI = decltype(multi_tag)::value;
+            int sp = wseg, knext = 0x7fffffff;
+            const int kb0 = kl + tl * LSP;
+            if (MULTI) {
+                while (sk0[sp + 1] <= kb0) sp++;
+                knext = sk0[sp + 1];
+            }
+            unsigned long long dfx = scar[sp].dfx;
+            unsigned long long phi = scar[sp].fx + (unsigned long long)(long long)(kb0 - sk0[sp]) * dfx;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int gl = tl * NIT + it, g = g0 + r * RGRP + gl;
@@ -799,22 +789,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int i = 0; i < SPG; i++) {
-                    unsigned long long ph = phi;
-                    if (FLIP) ph += (((kb + i < u.kflip) ? (u.neg & 1) : (u.neg >> 1)) ? GC_FX_BIAS : 0ULL);
+                    if (MULTI) {
+                        if (kb + i == knext) {          // the next piece starts at this sample
+                            sp++;
+                            phi = scar[sp].fx;
+                            dfx = scar[sp].dfx;
+                            knext = sk0[sp + 1];
+                        }
+                    }
                     const int pos = DTYPE == 2 ? (i & 1) : (i & 3);
-                    const uint2 l = lut[32 * pos + (int)(ph >> 59)];
+                    const uint2 l = lut[32 * pos + (int)(phi >> 59)];
                     const unsigned wd = w[DTYPE == 2 ? i >> 1 : i >> 2];
                     aI = __builtin_amdgcn_sdot4((int)wd, (int)l.x, aI, false);
                     aQ = __builtin_amdgcn_sdot4((int)wd, (int)l.y, aQ, false);
                     const int p = it * SPG + i + 1;
                     if (p < LSP) loc[tl * LPAD + p] = make_int2(aI, aQ);
-                    phi += ps;
+                    phi += dfx;
                 }
             }
         };
-        if (!(ablate & 2)) { if (flip) run(std::true_type{}); else run(std::false_type{}); }
+        if (!(ablate & 2)) { if (onepiece) run(std::false_type{}); else run(std::true_type{}); }
         // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
-        if (q < q1) js = edge_js(ed, ew) - roff;
+        if (q < q1) js = edge_js(ed, ew, rhint) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
         // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
         // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
@@ -873,11 +869,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
                     }
                 }
                 q += 256;
-                if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(ed, ew) - roff; }
+                if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(ed, ew, rhint) - roff; }
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
-        phir += psr;
         if (r == 1) GC_STAMP(6);
         if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
         if (r == 1) GC_STAMP(1);
@@ -970,7 +965,7 @@ int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8);
 int g_trk_algo = 0;     // 1 = prefix-sum form (default), 2 = replica form (GNSSCORR_TRK_ALGO=replica)
 
 template <int DTYPE, int NTAP, int NIT>
-int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial,
+int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, const GcRound *rounds, int *partial,
                    int nch, int nepoch, int nseg, int ntap_stride, int ntap_lo, int max_n)
 {
     static_assert(PsLayout<DTYPE, NIT>::bytes(NTAP) <= 64 * 1024, "static LDS image");
@@ -979,19 +974,20 @@ int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, co
     const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
     if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
     hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), 0, st, chan, unit,
-                       rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
+                       segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
 template <int DTYPE, int NTAP, int NIT>
-int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *partial, int nch, int nepoch,
+int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, int *partial, int nch, int nepoch,
                 int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
 {
     constexpr int RED_BYTES = ((4 * 2 * NTAP * 4) + 15) & ~15;
     constexpr int SEGS = 256 * NIT * (16 / DTYPE);
     constexpr int RS = SEGS / 8 + 64;
-    const int lds = (int)((DTYPE == 2 ? 512 : 1024) + RED_BYTES + 8 * RS * 4);
+    const int lds = (int)((DTYPE == 2 ? 512 : 1024) + RED_BYTES + 8 * RS * 4 + ((GC_NCAR + 4) & ~3) * 4 +
+                          GC_NCAR * sizeof(GcCarSeg) + GC_NCODE * sizeof(GcCodeSeg));
     static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
     if (lds > 64 * 1024)
         GC_HIP(hipFuncSetAttribute((const void *)trk_corr_kernel<DTYPE, NTAP, NIT>,
@@ -999,34 +995,34 @@ int launch_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, int *
     const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
     if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
     dim3 grid((unsigned)total), block(256);
-    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP, NIT>), grid, block, lds, st, chan, unit, partial, nch, nepoch,
+    hipLaunchKernelGGL((trk_corr_kernel<DTYPE, NTAP, NIT>), grid, block, lds, st, chan, unit, segs, partial, nch, nepoch,
                        nseg, ntap_stride, ntap_lo, max_n, ablate);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
 template <int DTYPE, int NTAP>
-int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch, int nepoch,
+int launch_corr_nit(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, const GcRound *rounds, int *partial, int nch, int nepoch,
                     int nseg, int ntap_stride, int ntap_lo, int max_n, int smax_max)
 {
     if (g_trk_algo == 1) {
         if (g_trk_nit == 1 || DTYPE == 1)
-            return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
-        return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+            return launch_corr_ps<DTYPE, NTAP, 1>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
+        return launch_corr_ps<DTYPE, NTAP, DTYPE == 1 ? 1 : 2>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n);
     }
     switch (g_trk_nit) {
-    default: return launch_corr<DTYPE, NTAP, 2>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
-    case 8: return launch_corr<DTYPE, NTAP, 8>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
-    case 4: return launch_corr<DTYPE, NTAP, 4>(st, chan, unit, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    default: return launch_corr<DTYPE, NTAP, 2>(st, chan, unit, segs, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    case 8: return launch_corr<DTYPE, NTAP, 8>(st, chan, unit, segs, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
+    case 4: return launch_corr<DTYPE, NTAP, 4>(st, chan, unit, segs, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, smax_max);
     }
 }
 
 template <int DTYPE>
-int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch, int nepoch,
+int launch_corr_taps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, const GcRound *rounds, int *partial, int nch, int nepoch,
                      int nseg, int ntap_stride, int ntap, int max_n, int smax_max)
 {
     // smallest instantiation that holds ntap accumulators; it serves (lo, NTAP]
-#define GC_LC(N, LO) return launch_corr_nit<DTYPE, N>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, LO, max_n, smax_max)
+#define GC_LC(N, LO) return launch_corr_nit<DTYPE, N>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, LO, max_n, smax_max)
     if (ntap <= 3)  GC_LC(3, 0);
     if (ntap <= 5)  GC_LC(5, 3);
     if (ntap <= 7)  GC_LC(7, 5);
@@ -1065,34 +1061,35 @@ int gc_trk_nseg(int dtype, int max_n)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch)
 {
-    hipLaunchKernelGGL(trk_plan_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, chan, state_in, state_out, plan,
+    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(64), 0, st, chan, state_in, state_out, plan,
                        nch, nepoch);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
-int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit,
-                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n)
+int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit, GcUnitSegs *segs,
+                         int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n, int *nco_overflow)
 {
     trk_pick_nit();
     const int total = nch * nepoch;
-    hipLaunchKernelGGL(trk_expand_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, plan, unit, nsamp_out,
-                       nch, nepoch, g_trk_algo == 1 ? rounds : (GcRound *)nullptr, nseg, max_n, g_trk_nit);
+    hipLaunchKernelGGL(trk_expand_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, plan, unit, segs, nsamp_out,
+                       nch, nepoch, g_trk_algo == 1 ? rounds : (GcRound *)nullptr, nseg, max_n, g_trk_nit, nco_overflow);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
 // One launch serves every channel whose (dtype, tap bucket) matches; callers
 // invoke it once per distinct dtype present in the channel set.
-int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcRound *rounds, int *partial, int nch,
+int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs,
+                       const GcRound *rounds, int *partial, int nch,
                        int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max)
 {
     trk_pick_nit();
     if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_corr: tap offset %d samples (<= 64 supported)", smax_max);
     if (dtype == 2)
-        return launch_corr_taps<2>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<2>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     if (dtype == 1)
-        return launch_corr_taps<1>(st, chan, unit, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+        return launch_corr_taps<1>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     return gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
 }
 

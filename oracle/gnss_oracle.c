@@ -151,61 +151,6 @@ double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
     return phase_remainder(phi);
 }
 
-/* Closed form implemented by the HIP kernels: a 64-bit fixed-point NCO.  One
- * LUT revolution (32 steps) is 2^64, i.e. 59 fractional bits per LUT step:
- *   A0 = trunc(fmod(phi0*32/2pi, 32) * 2^59),  PS = rint(ps * 2^59)
- *   N_k = A0 + k*PS  (exact integer),  index = trunc_toward_zero(N_k / 2^59) & 31
- * which is the reference's ((int)phi)&31 evaluated in exact arithmetic (the step
- * is quantised to 2^-59 LUT steps, ~1e-14 steps over a code period).  Negative
- * phases truncate toward zero like the C cast (ref src/sdrcmn.c:654,661).
- * The phase remainder stays the fp64 closed form of the running sum. */
-void orc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0, uint64_t *PS, int *kflip,
-                    int *neg0, int *neg1)
-{
-    const double phis = phi0 * ORC_CDIV / ORC_DPI;
-    const double ps = freq * ORC_CDIV * ti;
-    const double am = fmod(phis, 32.0);                       /* exact, sign of phis */
-    const double mag = ldexp(fabs(am), 59);                   /* < 2^64 */
-    const uint64_t a = (uint64_t)mag;                         /* truncation */
-    const long long p = llrint(ldexp(ps, 59));                /* |ps| < 16 */
-    const uint64_t pm = (uint64_t)(p < 0 ? -p : p);
-    *A0 = am < 0 ? (uint64_t)0 - a : a;
-    *PS = (uint64_t)p;
-    *neg0 = am < 0;
-    *neg1 = p < 0;
-    if (a == 0) *neg0 = *neg1;                                /* phase starts at exactly 0 */
-    if (pm == 0 || *neg0 == *neg1) { *kflip = 0x7fffffff; *neg1 = *neg0; }
-    else {
-        const uint64_t kf = a / pm + (a % pm != 0);           /* first k with |k*PS| >= |A0| */
-        *kflip = kf > 0x7fffffffULL ? 0x7fffffff : (int)kf;
-    }
-}
-
-static inline int carrier_index(uint64_t A0, uint64_t PS, int kflip, int neg0, int neg1, int k)
-{
-    const uint64_t phi = A0 + (uint64_t)(long long)k * PS;    /* mod 2^64 = mod 32 LUT steps */
-    const int neg = k < kflip ? neg0 : neg1;
-    return (int)((phi + (neg ? ((1ULL << 59) - 1) : 0)) >> 59);
-}
-
-double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
-                      double freq, double phi0, short *I, short *Q)
-{
-    short cost[ORC_CDIV], sint[ORC_CDIV];
-    double phis = phi0 * ORC_CDIV / ORC_DPI;
-    double ps = freq * ORC_CDIV * ti;
-    double prem;
-    uint64_t A0, PS;
-    int kflip, neg0, neg1, k;
-    orc_carrier_lut(cost, sint);
-    orc_carrier_fx(phi0, freq, ti, &A0, &PS, &kflip, &neg0, &neg1);
-    for (k = 0; k < n; k++)
-        mix_one(data, dtype, k, carrier_index(A0, PS, kflip, neg0, neg1, k), cost, sint, I, Q);
-    prem = fma((double)n, ps, phis) * ORC_DPI / ORC_CDIV;
-    if (prem > ORC_DPI) prem = fma(-floor(prem / ORC_DPI), ORC_DPI, prem);
-    return prem;
-}
-
 /* ------------------------------------------------------------------------- */
 /* code resampling                                                           */
 /* ------------------------------------------------------------------------- */
@@ -222,26 +167,6 @@ double orc_rescode_seq(const short *code, int len, double coff, int smax,
         rcode[j] = code[(int)coff];
     }
     return coff - smax * ci;
-}
-
-/* closed form implemented by the HIP kernels: c_j = fma(j, ci, c_0),
- * chip = trunc(c_j) mod len; the returned remainder subtracts exactly the
- * wraps the reference loop would have applied (those seen at the top of its
- * last iteration), so it may be >= len like the reference's. */
-double orc_rescode_cf(const short *code, int len, double coff, int smax,
-                      double ci, int n, short *rcode)
-{
-    int j, nt = n + 2 * smax;
-    double cend, wraps = 0.0;
-    coff -= smax * ci;
-    coff -= floor(coff / len) * len;
-    for (j = 0; j < nt; j++) {
-        long long t = (long long)fma((double)j, ci, coff);
-        rcode[j] = code[t % len];
-    }
-    if (nt > 0) wraps = (double)((long long)fma((double)(nt - 1), ci, coff) / len);
-    cend = fma((double)nt, ci, coff) - wraps * len;
-    return cend - smax * ci;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -266,8 +191,7 @@ static void dot_taps(const short *a1, const short *a2, const short *const *b,
 void orc_correlator(const signed char *data, int dtype, double ti, int n,
                     double freq, double phi0, double crate, double coff,
                     const int *s, int ns, double *II, double *QQ,
-                    double *remc, double *remp, const short *codein, int coden,
-                    int mode)
+                    double *remc, double *remp, const short *codein, int coden)
 {
     int smax = s[ns - 1], i;
     short *dI = (short *)malloc(sizeof(short) * (size_t)(n + 64));
@@ -277,13 +201,8 @@ void orc_correlator(const signed char *data, int dtype, double ti, int n,
     if (!dI || !dQ || !ce) { free(dI); free(dQ); free(ce); return; }
     code = ce + smax;
 
-    if (mode) {
-        *remp = orc_mixcarr_cf(data, dtype, ti, n, freq, phi0, dI, dQ);
-        *remc = orc_rescode_cf(codein, coden, coff, smax, ti * crate, n, ce);
-    } else {
-        *remp = orc_mixcarr_seq(data, dtype, ti, n, freq, phi0, dI, dQ);
-        *remc = orc_rescode_seq(codein, coden, coff, smax, ti * crate, n, ce);
-    }
+    *remp = orc_mixcarr_seq(data, dtype, ti, n, freq, phi0, dI, dQ);
+    *remc = orc_rescode_seq(codein, coden, coff, smax, ti * crate, n, ce);
     /* P, E1, L1 then (Ei, Li) pairs: ref :712-715 */
     b[0] = code; b[1] = code - s[0]; b[2] = code + s[0];
     dot_taps(dI, dQ, b, 3, n, II, QQ);
@@ -451,7 +370,7 @@ void orc_codespectrum(const short *code, int clen, double ci, int nsamp,
  * (m = 2n: the "zero padding" memset is overwritten completely). */
 void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
                      const double *freq, int nfreq, double crate, int m,
-                     const float *codex, double *P, int mode)
+                     const float *codex, double *P)
 {
     signed char *dR = (signed char *)calloc((size_t)m * dtype, 1);
     short *dI = (short *)malloc(sizeof(short) * (size_t)(m + 64));
@@ -461,8 +380,7 @@ void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
     (void)crate;
     memcpy(dR, data, (size_t)2 * n * dtype);
     for (i = 0; i < nfreq; i++) {
-        if (mode) orc_mixcarr_cf(dR, dtype, ti, m, freq[i], 0.0, dI, dQ);
-        else      orc_mixcarr_seq(dR, dtype, ti, m, freq[i], 0.0, dI, dQ);
+        orc_mixcarr_seq(dR, dtype, ti, m, freq[i], 0.0, dI, dQ);
         orc_cpxcpx(dI, dQ, ORC_CSCALE / m, m, dx);
         orc_cpxconv(dx, codex, m, n, 1, &P[(size_t)i * n]);
     }
@@ -474,7 +392,7 @@ void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
 void orc_pcorrelator_td(const signed char *data, int dtype, double ti, int n,
                         const double *freq, int nfreq, int m,
                         const short *code, int clen, double ci,
-                        int k0, int k1, double *P, int mode)
+                        int k0, int k1, double *P)
 {
     short *dI = (short *)malloc(sizeof(short) * (size_t)(m + 64));
     short *dQ = (short *)malloc(sizeof(short) * (size_t)(m + 64));
@@ -482,8 +400,7 @@ void orc_pcorrelator_td(const signed char *data, int dtype, double ti, int n,
     int b, k, j;
     orc_rescode_seq(code, clen, 0.0, 0, ci, n, rc);
     for (b = 0; b < nfreq; b++) {
-        if (mode) orc_mixcarr_cf(data, dtype, ti, m, freq[b], 0.0, dI, dQ);
-        else      orc_mixcarr_seq(data, dtype, ti, m, freq[b], 0.0, dI, dQ);
+        orc_mixcarr_seq(data, dtype, ti, m, freq[b], 0.0, dI, dQ);
         for (k = k0; k < k1; k++) {
             double sr = 0.0, si = 0.0, sc = 32.0 * (double)m;
             for (j = 0; j < n; j++) {
@@ -618,7 +535,7 @@ int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
 
 /* ref src/sdracq.c:14-62 */
 uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
-                            double *power, int mode, int *iters_done)
+                            double *power, int *iters_done)
 {
     signed char *data = (signed char *)malloc((size_t)2 * ch->nsamp * ch->dtype);
     uint64_t buffloc = ring->wrpos - (uint64_t)(ch->intg + 1) * ch->nsamp;
@@ -627,7 +544,7 @@ uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
         orc_getbuff(ring, buffloc, 2 * ch->nsamp, ch->dtype, data);
         buffloc += ch->nsamp;
         orc_pcorrelator(data, ch->dtype, ch->ti, ch->nsamp, ch->freq, ch->nfreq,
-                        ch->crate, ch->nfft, ch->xcode, power, mode);
+                        ch->crate, ch->nfft, ch->xcode, power);
         if (orc_checkacquisition(power, ch->nsamp, ch->nfreq, ch->nsampchip,
                                  ch->ctime, ch->freq, &ch->acq)) {
             ch->flagacq = 1;
@@ -648,7 +565,7 @@ uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
  * and trk.II as its "QQ" (:42), and the old-value memcpy copies
  * 1+2*corrn*sizeof(double) bytes (:35-36); both kept. */
 uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
-                         uint64_t buffloc, int mode)
+                         uint64_t buffloc)
 {
     uint64_t bufflocnow = ring->wrpos - (uint64_t)ch->nsamp;
     ch->flagtrk = 0;
@@ -664,7 +581,7 @@ uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
         orc_correlator(data, ch->dtype, ch->ti, ch->currnsamp, ch->carrfreq,
                        ch->oldremcarr, ch->codefreq, ch->oldremcode, ch->corrp,
                        ch->corrn, ch->QQ, ch->II, &ch->remcode, &ch->remcarr,
-                       ch->code, ch->clen, mode);
+                       ch->code, ch->clen);
         ch->flagtrk = 1;
         free(data);
     }

@@ -15,15 +15,9 @@
  * known answers it is checked against are the IS-GPS-200 C/A "first 10 chips"
  * octal table (tests/golden/ca_first10_octal.json) and numpy's FFT.
  *
- * Two flavours of the two NCOs are provided:
- *   *_seq : literal restatement (phase/code offset advanced by repeated += in
- *           fp64, exactly as the reference loops do);
- *   *_cf  : the closed form the HIP kernels implement (carrier: 64-bit
- *           fixed-point NCO, exact arithmetic; code: chip = trunc(fma(j, ci,
- *           c_0))); identical mathematics, differs from _seq only through the
- *           fp64 rounding of _seq's running sums.
- * GPU results are compared bit-exactly with _cf and to 1e-4 relative
- * (north_star tolerance) with _seq.
+ * The two NCOs are restated literally (*_seq: phase / code offset advanced by
+ * repeated += in fp64, exactly as the reference loops do); GPU results are
+ * compared with them bit for bit.
  */
 #ifndef GNSS_ORACLE_H
 #define GNSS_ORACLE_H
@@ -46,28 +40,20 @@ extern "C" {
 /* ref src/sdrcode.c:101-154, :426-444, :523-539 */
 int orc_gencode(int prn, int ctype, short *code, int *len, double *crate);
 
-/* ref src/sdrcmn.c:633-669 (literal) and closed form */
+/* ref src/sdrcmn.c:633-669 */
 void   orc_carrier_lut(short *cost, short *sint);
 double orc_mixcarr_seq(const signed char *data, int dtype, double ti, int n,
                        double freq, double phi0, short *I, short *Q);
-double orc_mixcarr_cf(const signed char *data, int dtype, double ti, int n,
-                      double freq, double phi0, short *I, short *Q);
-/* start value / step / sign bookkeeping of the closed form's fixed-point carrier NCO */
-void orc_carrier_fx(double phi0, double freq, double ti, uint64_t *A0, uint64_t *PS, int *kflip,
-                    int *neg0, int *neg1);
 
-/* ref src/sdrcmn.c:608-621 (literal) and closed form */
+/* ref src/sdrcmn.c:608-621 */
 double orc_rescode_seq(const short *code, int len, double coff, int smax,
                        double ci, int n, short *rcode);
-double orc_rescode_cf(const short *code, int len, double coff, int smax,
-                      double ci, int n, short *rcode);
 
-/* ref src/sdrcmn.c:687-722; mode 0 = seq NCOs, 1 = closed-form NCOs */
+/* ref src/sdrcmn.c:687-722 */
 void orc_correlator(const signed char *data, int dtype, double ti, int n,
                     double freq, double phi0, double crate, double coff,
                     const int *s, int ns, double *II, double *QQ,
-                    double *remc, double *remp, const short *code, int clen,
-                    int mode);
+                    double *remc, double *remp, const short *code, int clen);
 
 /* ref src/sdrcmn.c:185-195 */
 void orc_cpxcpx(const short *I, const short *Q, double scale, int n,
@@ -83,16 +69,16 @@ void orc_cpxpspec(float *cpx, int n, int flagsum, double *pspec);
 /* ref src/sdrinit.c:645-655 : xcode = FFT_nfft(zero-padded resampled code) */
 void orc_codespectrum(const short *code, int clen, double ci, int nsamp,
                       int nfft, float *xcode);
-/* ref src/sdrcmn.c:738-773; mode as orc_correlator */
+/* ref src/sdrcmn.c:738-773 */
 void orc_pcorrelator(const signed char *data, int dtype, double ti, int n,
                      const double *freq, int nfreq, double crate, int m,
-                     const float *codex, double *P, int mode);
+                     const float *codex, double *P);
 /* time-domain evaluation of the same quantity (SURVEY 8a normative form):
  * P[b][k] += |sum_j w[k+j] r[j]|^2/(32 m)^2, lags k in [k0,k1) only */
 void orc_pcorrelator_td(const signed char *data, int dtype, double ti, int n,
                         const double *freq, int nfreq, int m,
                         const short *code, int clen, double ci,
-                        int k0, int k1, double *P, int mode);
+                        int k0, int k1, double *P);
 
 /* ref src/sdrcmn.c:461-497, :574-578 */
 double orc_maxvd(const double *d, int n, int exinds, int exinde, int *ind);
@@ -151,10 +137,10 @@ int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
 /* ref src/sdracq.c:14-62 (no sleep, no printf); power = nsamp*nfreq zeroed
  * doubles; returns buffloc */
 uint64_t orc_sdracquisition(orc_chan_t *ch, const orc_ring_t *ring,
-                            double *power, int mode, int *iters_done);
+                            double *power, int *iters_done);
 /* ref src/sdrtrk.c:15-54 (without sdrnavigation); returns bufflocnow */
 uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
-                         uint64_t buffloc, int mode);
+                         uint64_t buffloc);
 /* ref src/sdrtrk.c:64-86 */
 void orc_cumsumcorr(orc_chan_t *ch, int polarity);
 void orc_clearcumsumcorr(orc_chan_t *ch);

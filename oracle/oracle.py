@@ -54,21 +54,19 @@ def lib():
     d, i, vp = C.c_double, C.c_int, C.c_void_p
     L.orc_gencode.argtypes = [i, i, vp, C.POINTER(i), C.POINTER(d)]
     L.orc_carrier_lut.argtypes = [vp, vp]
-    for f in (L.orc_mixcarr_seq, L.orc_mixcarr_cf):
-        f.restype = d
-        f.argtypes = [vp, i, d, i, d, d, vp, vp]
-    for f in (L.orc_rescode_seq, L.orc_rescode_cf):
-        f.restype = d
-        f.argtypes = [vp, i, d, i, d, i, vp]
+    L.orc_mixcarr_seq.restype = d
+    L.orc_mixcarr_seq.argtypes = [vp, i, d, i, d, d, vp, vp]
+    L.orc_rescode_seq.restype = d
+    L.orc_rescode_seq.argtypes = [vp, i, d, i, d, i, vp]
     L.orc_correlator.restype = None
-    L.orc_correlator.argtypes = [vp, i, d, i, d, d, d, d, vp, i, vp, vp, C.POINTER(d), C.POINTER(d), vp, i, i]
+    L.orc_correlator.argtypes = [vp, i, d, i, d, d, d, d, vp, i, vp, vp, C.POINTER(d), C.POINTER(d), vp, i]
     L.orc_cpxcpx.argtypes = [vp, vp, d, i, vp]
     L.orc_fft.argtypes = [vp, i, i]
     L.orc_cpxconv.argtypes = [vp, vp, i, i, i, vp]
     L.orc_cpxpspec.argtypes = [vp, i, i, vp]
     L.orc_codespectrum.argtypes = [vp, i, d, i, i, vp]
-    L.orc_pcorrelator.argtypes = [vp, i, d, i, vp, i, d, i, vp, vp, i]
-    L.orc_pcorrelator_td.argtypes = [vp, i, d, i, vp, i, i, vp, i, d, i, i, vp, i]
+    L.orc_pcorrelator.argtypes = [vp, i, d, i, vp, i, d, i, vp, vp]
+    L.orc_pcorrelator_td.argtypes = [vp, i, d, i, vp, i, i, vp, i, d, i, i, vp]
     L.orc_maxvd.restype = d
     L.orc_maxvd.argtypes = [vp, i, i, i, C.POINTER(i)]
     L.orc_meanvd.restype = d
@@ -77,9 +75,9 @@ def lib():
     L.orc_getbuff.argtypes = [C.POINTER(Ring), C.c_uint64, i, i, vp]
     L.orc_initchan.argtypes = [C.POINTER(Chan), i, i, i, d, d, d, i, i, i, vp, vp, vp]
     L.orc_sdracquisition.restype = C.c_uint64
-    L.orc_sdracquisition.argtypes = [C.POINTER(Chan), C.POINTER(Ring), vp, i, C.POINTER(i)]
+    L.orc_sdracquisition.argtypes = [C.POINTER(Chan), C.POINTER(Ring), vp, C.POINTER(i)]
     L.orc_sdrtracking.restype = C.c_uint64
-    L.orc_sdrtracking.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.c_uint64, i]
+    L.orc_sdrtracking.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.c_uint64]
     L.orc_cumsumcorr.argtypes = [C.POINTER(Chan), i]
     L.orc_clearcumsumcorr.argtypes = [C.POINTER(Chan)]
     L.orc_pll.argtypes = [C.POINTER(Chan), i, d]
@@ -96,7 +94,7 @@ def gencode(prn, ctype):
     return code[:n.value].copy(), cr.value
 
 
-def correlator(data, dtype, ti, n, freq, phi0, crate, coff, s, code, mode):
+def correlator(data, dtype, ti, n, freq, phi0, crate, coff, s, code):
     """-> (II, QQ, remc, remp) as the reference's correlator() returns them."""
     data = np.ascontiguousarray(data, np.int8)
     s = np.ascontiguousarray(s, np.int32)
@@ -106,7 +104,7 @@ def correlator(data, dtype, ti, n, freq, phi0, crate, coff, s, code, mode):
     remc, remp = C.c_double(), C.c_double()
     lib().orc_correlator(data.ctypes.data, dtype, ti, n, freq, phi0, crate, coff, s.ctypes.data, len(s),
                          II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code.ctypes.data,
-                         len(code), mode)
+                         len(code))
     return II, QQ, remc.value, remp.value
 
 

@@ -29,7 +29,7 @@ def data_for(seed, n, dtype, amp=90):
 
 
 def main():
-    out = {"note": "oracle-generated (closed-form NCO variant); inputs = numpy default_rng(seed).integers(-amp, amp+1)"
+    out = {"note": "oracle-generated (literal restatement: sequential fp64 NCOs); inputs = numpy default_rng(seed).integers(-amp, amp+1)"
                    " with the first four bytes set to -128,127,-128,127", "correlator": [], "acquisition": []}
     cases = [  # seed, dtype, n, freq, phi0, dcode, coff, taps, prn
         (101, 2, 16368, 2345.6, 0.0, 0.0, 0.0, [3, 6], 1),
@@ -41,7 +41,7 @@ def main():
     for seed, dtype, n, freq, phi0, dcode, coff, taps, prn in cases:
         code, crate = orc.gencode(prn, 1)
         d = data_for(seed, n, dtype)
-        II, QQ, remc, remp = orc.correlator(d, dtype, TI, n, freq, phi0, crate + dcode, coff, taps, code, 1)
+        II, QQ, remc, remp = orc.correlator(d, dtype, TI, n, freq, phi0, crate + dcode, coff, taps, code)
         out["correlator"].append(dict(seed=seed, dtype=dtype, n=n, freq=freq, phi0=phi0, codefreq=crate + dcode,
                                       coff=coff, taps=taps, prn=prn, amp=90, II=list(II), QQ=list(QQ),
                                       remc=remc, remp=remp))
@@ -64,7 +64,7 @@ def main():
         o.xcode = xc.ctypes.data
         P = np.zeros(o.nfreq * n)
         it = C.c_int()
-        b = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), P.ctypes.data, 1, C.byref(it))
+        b = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), P.ctypes.data, C.byref(it))
         out["acquisition"].append(dict(seed=seed, prn=prn, doppler=doppler, delay=delay, wrpos=wrpos,
                                        nsamples=nsamples, flagacq=o.flagacq, iters=it.value,
                                        acqcodei=o.acq.acqcodei, freqi=o.acq.freqi, acqfreq=o.acq.acqfreq,

@@ -13,8 +13,7 @@ int nco_carrier(double phi0, double freq, double ti, int n, int cap, int *idx, d
     GcCarSeg seg[256];
     if (cap > 256) cap = 256;
     GcCarTable t{k0, seg, cap, 0, 0};
-    struct Ref { GcCarTable *t; void operator()(int k, double x, double d, int c) const { (*t)(k, x, d, c); } } r{&t};
-    const double xn = gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, r);
+    const double xn = gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, t);
     *prem = gc_carrier_prem(xn);
     if (t.overflow) return -1;
     for (int k = 0; k < n; k++) idx[k] = gc_carrier_idx_at(k0, seg, t.n, k);
@@ -27,9 +26,8 @@ int nco_code(int len, double coff, int smax, double ci, int n, int cap, int *chi
     GcCodeSeg seg[256];
     if (cap > 256) cap = 256;
     GcCodeTable t{seg, cap, 0, 0};
-    struct Ref { GcCodeTable *t; void operator()(int j, double y, double d, int c, int w) const { (*t)(j, y, d, c, w); } } r{&t};
     const int nt = n + 2 * smax;
-    const double cend = gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, nt, r);
+    const double cend = gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, nt, t);
     *rem = gc_code_rem(cend, smax, ci);
     if (t.overflow) return -1;
     for (int j = 0; j < nt; j++) chip[j] = gc_code_chip_at(seg, t.n, j, nullptr);
@@ -40,8 +38,9 @@ int nco_code(int len, double coff, int smax, double ci, int n, int cap, int *chi
 void nco_chain(double phi0, double freq, double ti, int n, int len, double coff, int smax, double ci,
                double *prem, double *rem)
 {
-    *prem = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, GcNoEmit()));
-    *rem = gc_code_rem(gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, n + 2 * smax, GcNoEmit()), smax, ci);
+    GcNoEmit ne;
+    *prem = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, ne));
+    *rem = gc_code_rem(gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, n + 2 * smax, ne), smax, ci);
 }
 
 }

@@ -53,7 +53,7 @@ def _worker(rank, world, port, nsamples, prns, out_q):
         b = 10 + i
         rows = []
         for e in range(3):
-            orc.lib().orc_sdrtracking(C.byref(o), C.byref(r), b, 1)
+            orc.lib().orc_sdrtracking(C.byref(o), C.byref(r), b)
             rows.append([o.II[t] for t in range(5)] + [o.QQ[t] for t in range(5)])
             b += o.currnsamp
         res[i] = rows
@@ -102,6 +102,6 @@ def test_two_rank_gloo_matches_single_process(gc, orc):
         o.carrfreq, o.codefreq, o.remcode, o.remcarr = 500.0 * (i + 1), o.crate + 0.1 * i, 0.1 * i + 0.05, 0.2 * i
         b = 10 + i
         for e in range(3):
-            orc.lib().orc_sdrtracking(C.byref(o), C.byref(ring), b, 1)
+            orc.lib().orc_sdrtracking(C.byref(o), C.byref(ring), b)
             assert merged[i][e] == [o.II[t] for t in range(5)] + [o.QQ[t] for t in range(5)]
             b += o.currnsamp

@@ -34,7 +34,7 @@ def _acq_signal(v, code):
 def test_oracle_reproduces_correlator_vectors(orc, v):
     code, _ = orc.gencode(v["prn"], 1)
     II, QQ, remc, remp = orc.correlator(_data(v), v["dtype"], TI, v["n"], v["freq"], v["phi0"], v["codefreq"],
-                                        v["coff"], v["taps"], code, 1)
+                                        v["coff"], v["taps"], code)
     assert list(II) == v["II"] and list(QQ) == v["QQ"] and remc == v["remc"] and remp == v["remp"]
 
 

@@ -70,7 +70,7 @@ def test_acquisition_matches_oracle(gc, orc, synth, engine, dtype, f_if):
         o.xcode = xc.ctypes.data
         power = np.zeros(o.nfreq * o.nsamp)
         iters = C.c_int()
-        buffloc = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), power.ctypes.data, 1, C.byref(iters))
+        buffloc = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), power.ctypes.data, C.byref(iters))
         r = res[i]
         assert r["flagacq"] == o.flagacq, (p, r, o.acq.peakr)
         assert r["flagacq"] == (1 if p in (3, 20) else 0)

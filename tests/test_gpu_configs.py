@@ -40,7 +40,7 @@ def _oracle_acq(orc, o, data, nsamples, wrpos):
     o.xcode = xc.ctypes.data
     power = np.zeros(o.nfreq * o.nsamp)
     iters = C.c_int()
-    buffloc = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), power.ctypes.data, 1, C.byref(iters))
+    buffloc = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), power.ctypes.data, C.byref(iters))
     return buffloc, iters.value
 
 
@@ -102,7 +102,7 @@ def test_gps_plus_glonass_on_two_streams(gc, orc, synth, engine):
         o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
         buffloc = st["buffloc"]
         for e in range(nep):
-            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc, 1)
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc)
             assert o.flagtrk == 1 and o.currnsamp == ns[i, e]
             assert np.array_equal(np.ctypeslib.as_array(o.II)[:5], II[i, e])
             assert np.array_equal(np.ctypeslib.as_array(o.QQ)[:5], QQ[i, e])
@@ -159,7 +159,7 @@ def test_fine_doppler_grid_and_10ms_sums(gc, orc, synth, engine):
         L.orc_clearcumsumcorr(C.byref(o))
         buffloc = st["buffloc"]
         for e in range(10):
-            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc, 1)
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc)
             L.orc_cumsumcorr(C.byref(o), 1)
             buffloc += o.currnsamp
         assert np.array_equal(np.ctypeslib.as_array(o.sumI)[:5], sI[i])
@@ -190,6 +190,6 @@ def test_mixed_sample_formats_in_one_engine(gc, orc, engine):
     II, QQ, ns = engine.trk_fetch()
     for i, (p, dt, ft, fi) in enumerate(spec):
         o = orc.make_chan(p, dtype=dt, f_if=fi)
-        oII, oQQ, ons, _ = _oracle_run(orc, [o], [states[i]], d_iq if dt == 2 else d_re, nsamp, nsamp, 5, mode=1)
+        oII, oQQ, ons, _ = _oracle_run(orc, [o], [states[i]], d_iq if dt == 2 else d_re, nsamp, nsamp, 5)
         assert np.array_equal(ns[i], ons[0])
         assert np.array_equal(II[i], oII[0]) and np.array_equal(QQ[i], oQQ[0])

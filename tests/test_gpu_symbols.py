@@ -16,20 +16,26 @@ TI = 1 / 16.368e6
 def test_mixcarr_rescode_cpxcpx(gc, orc):
     L, O = gc.lib(), orc.lib()
     rng = np.random.default_rng(0)
-    for dtype, freq, phi0 in ((2, 1234.5, 0.4), (1, 4.092e6 - 700.0, 0.0), (2, -3.9e6, 2.0)):
-        n = 5000
+    # incl. the acquisition hand-over state (phase 0, bin-centre frequencies: ref src/sdracq.c:51-55) and
+    # a negative, never-wrapped phase (ref src/sdrcmn.c:667)
+    for dtype, freq, phi0 in ((2, 1234.5, 0.4), (1, 4.092e6 - 700.0, 0.0), (2, -3.9e6, 2.0), (2, 2200.0, 0.0),
+                              (2, -1400.0, 0.0), (1, 4.0932e6, 0.0), (2, -3400.0, -12345.678), (2, 137.77, 6.1)):
+        n = 16369
         data = rng.integers(-128, 128, size=n * dtype, dtype=np.int8)
         I, Q, oI, oQ = (np.zeros(n, np.int16) for _ in range(4))
         r = L.mixcarr(data.ctypes.data, dtype, TI, n, freq, phi0, I.ctypes.data, Q.ctypes.data)
-        ro = O.orc_mixcarr_cf(data.ctypes.data, dtype, TI, n, freq, phi0, oI.ctypes.data, oQ.ctypes.data)
+        ro = O.orc_mixcarr_seq(data.ctypes.data, dtype, TI, n, freq, phi0, oI.ctypes.data, oQ.ctypes.data)
         assert np.array_equal(I, oI) and np.array_equal(Q, oQ) and r == ro
     code, crate = orc.gencode(3, 1)
-    for coff, smax, dc in ((0.0, 0, 0.0), (100.25, 6, 1.5), (1022.9, 18, -2.0)):
+    # incl. an integer code phase with a non-dyadic chip step: the chip choice hinges on the rounding of
+    # the reference's running sum (ref src/sdrcmn.c:616-619)
+    for coff, smax, dc in ((0.0, 0, 0.0), (100.25, 6, 1.5), (1022.9, 18, -2.0), (0.0, 6, 1.7), (0.0, 18, -2.3),
+                           (512.0, 6, 0.4), (1022.9999999, 3, 2.9)):
         n = 16368
         a, b = np.zeros(n + 2 * smax, np.int16), np.zeros(n + 2 * smax, np.int16)
         ci = TI * (crate + dc)
         r = L.rescode(code.ctypes.data, 1023, coff, smax, ci, n, a.ctypes.data)
-        ro = O.orc_rescode_cf(code.ctypes.data, 1023, coff, smax, ci, n, b.ctypes.data)
+        ro = O.orc_rescode_seq(code.ctypes.data, 1023, coff, smax, ci, n, b.ctypes.data)
         assert np.array_equal(a, b) and r == ro
     I = rng.integers(-8000, 8000, size=1000).astype(np.int16)
     Q = rng.integers(-8000, 8000, size=1000).astype(np.int16)
@@ -75,7 +81,7 @@ def test_cpxconv_and_pcorrelator_reference_length(gc, orc):
     Po = P.copy()
     L.pcorrelator(data.ctypes.data, 2, o.ti, n, freq.ctypes.data, 3, o.crate, m, xc.ctypes.data, P.ctypes.data)
     O.orc_pcorrelator(data.ctypes.data, 2, o.ti, n, freq.ctypes.data, 3, o.crate, m, xc.ctypes.data,
-                      Po.ctypes.data, 1)
+                      Po.ctypes.data)
     assert rel_err(P, Po) < 1e-4
     a = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
     b = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
@@ -157,7 +163,7 @@ def test_sdracquisition_then_sdrtracking_like_sdrthread(gc, orc, synth, tmp_path
     ring.buff, ring.ringlen, ring.wrpos = big.ctypes.data, ringlen, nsamples
     opower = np.zeros(71 * 16368)
     it = C.c_int()
-    obuffloc = O.orc_sdracquisition(C.byref(o), C.byref(ring), opower.ctypes.data, 1, C.byref(it))
+    obuffloc = O.orc_sdracquisition(C.byref(o), C.byref(ring), opower.ctypes.data, C.byref(it))
     assert sdr.flagacq == o.flagacq == 1 and buffloc == obuffloc
     assert (sdr.acq.acqcodei, sdr.acq.freqi, sdr.acq.acqfreq) == (o.acq.acqcodei, o.acq.freqi, o.acq.acqfreq)
     assert abs(sdr.acq.acqfreq - 4.092e6 - 2210.0) <= 100.0
@@ -172,7 +178,7 @@ def test_sdracquisition_then_sdrtracking_like_sdrthread(gc, orc, synth, tmp_path
     cnt, IP = 0, []
     for _ in range(12):
         L.sdrtracking(C.byref(sdr), buffloc, cnt)
-        O.orc_sdrtracking(C.byref(o), C.byref(ring), obuffloc, 1)
+        O.orc_sdrtracking(C.byref(o), C.byref(ring), obuffloc)
         assert sdr.flagtrk == o.flagtrk == 1 and sdr.currnsamp == o.currnsamp
         for t in range(13):
             assert sdr.trk.II[t] == o.II[t] and sdr.trk.QQ[t] == o.QQ[t]

@@ -1,8 +1,8 @@
 """HIP tracking correlators vs the CPU oracle (parity tests proper, -m gpu).
 
-Bar: bit-exact against the oracle's closed-form NCO variant (integer
-accumulators), and within 1e-4 relative (north_star tolerance) of the literal
-sequential-NCO restatement of the reference (ref src/sdrcmn.c:608-722)."""
+Bar: bit-exact -- E/P/L sums, samples per period and the chained remainders --
+against the literal restatement of the reference, whose carrier and code NCOs
+advance by one rounded fp64 addition per sample (ref src/sdrcmn.c:608-722)."""
 import ctypes as C
 
 import numpy as np
@@ -29,13 +29,13 @@ def _setup(gc, orc, engine, dtype, f_if, corrn, corrd, corrp, prns, nsamples, se
     engine.set_channels(chans)
     states, ochs = [], []
     for i, c in enumerate(chans):
-        # channel 0 starts like a channel fresh out of acquisition (remcode = remcarr = 0,
-        # codefreq = crate: ref src/sdracq.c:54-55), the others mid-track.  A code phase that
-        # is an exact integer with a non-dyadic chip step is avoided: there the reference's
-        # own chip choice hinges on the rounding of its running fp64 sum.
-        st = dict(carrfreq=f_if + rng.uniform(-5000, 5000),
+        # channel 0 starts like a channel fresh out of acquisition (remcode = remcarr = 0, carrfreq on
+        # the 200 Hz grid, codefreq = crate: ref src/sdracq.c:51-55), channel 1 with an integer code phase
+        # and a non-dyadic chip step (the chip choice hinges on the rounding of the reference's running
+        # sum), the others mid-track
+        st = dict(carrfreq=f_if + (rng.uniform(-5000, 5000) if i else 2200.0),
                   codefreq=c.crate + (rng.uniform(-3, 3) if i else 0.0),
-                  remcode=rng.uniform(0.01, 0.99) if i else 0.0, remcarr=rng.uniform(0, 6.2) if i else 0.0,
+                  remcode=(rng.uniform(0.01, 0.99) if i > 1 else 0.0), remcarr=rng.uniform(0, 6.2) if i else 0.0,
                   buffloc=buffloc0 + 1000 * i + (i % 3))
         states.append(st)
         o = orc.make_chan(c.prn, dtype=dtype, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
@@ -44,7 +44,7 @@ def _setup(gc, orc, engine, dtype, f_if, corrn, corrd, corrp, prns, nsamples, se
     return data, chans, states, ochs
 
 
-def _oracle_run(orc, ochs, states, data, ringlen, wrpos, nepoch, mode):
+def _oracle_run(orc, ochs, states, data, ringlen, wrpos, nepoch):
     ring = orc.make_ring(data, ringlen, wrpos)
     L = orc.lib()
     ntap = 1 + 2 * ochs[0].corrn
@@ -56,7 +56,7 @@ def _oracle_run(orc, ochs, states, data, ringlen, wrpos, nepoch, mode):
         o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
         buffloc = st["buffloc"]
         for e in range(nepoch):
-            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc, mode)
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc)
             assert o.flagtrk == 1
             II[i, e] = np.ctypeslib.as_array(o.II)[:ntap]
             QQ[i, e] = np.ctypeslib.as_array(o.QQ)[:ntap]
@@ -81,18 +81,12 @@ def test_trk_batch_matches_oracle(gc, orc, engine, dtype, f_if, corrn, corrd, co
     engine.trk_run(nepoch)
     II, QQ, ns = engine.trk_fetch()
     fin = engine.trk_get_state()
-    # closed-form oracle: bit exact
-    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=1)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch)
     assert np.array_equal(ns, ons)
     assert np.array_equal(II, oII)
     assert np.array_equal(QQ, oQQ)
     for a, b in zip(fin, ofin):
         assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
-    # literal (sequential NCO) oracle: north_star tolerance 1e-4 relative
-    sII, sQQ, sns, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=0)
-    assert np.array_equal(ns, sns)
-    assert rel_err(II, sII) <= 1e-4
-    assert rel_err(QQ, sQQ) <= 1e-4
     # cumsumcorr over the batch (ref src/sdrtrk.c:64-76)
     sI, sQ = engine.trk_fetch_sums()
     assert np.array_equal(sI, II.sum(axis=1))
@@ -112,7 +106,7 @@ def test_trk_ring_wrap(gc, orc, engine):
     engine.trk_set_state(states)
     engine.trk_run(2)
     II, QQ, ns = engine.trk_fetch()
-    oII, oQQ, ons, _ = _oracle_run(orc, ochs, states, data, ringlen, 3 * ringlen, 2, mode=1)
+    oII, oQQ, ons, _ = _oracle_run(orc, ochs, states, data, ringlen, 3 * ringlen, 2)
     assert np.array_equal(ns, ons) and np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
 
 
@@ -131,13 +125,9 @@ def test_correlator_symbol(gc, orc):
         L.correlator(data.ctypes.data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s.ctypes.data, 3,
                      II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code16.ctypes.data, 1023)
         oII, oQQ, orc_c, orc_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s,
-                                                code16, 1)
+                                                code16)
         assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
         assert remc.value == orc_c and remp.value == orc_p
-        sII, sQQ, src_c, src_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 0.7, crate + 1.5, 100.25, s,
-                                                code16, 0)
-        assert rel_err(II, sII) <= 1e-4 and rel_err(QQ, sQQ) <= 1e-4
-        assert abs(remc.value - src_c) <= 1e-6 and abs(remp.value - src_p) <= 1e-6
 
 
 def test_consecutive_batches_and_lookahead_planner(gc, orc, engine):
@@ -155,7 +145,7 @@ def test_consecutive_batches_and_lookahead_planner(gc, orc, engine):
         got_QQ.append(QQ)
     II = np.concatenate(got_II, axis=1)
     QQ = np.concatenate(got_QQ, axis=1)
-    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 11, mode=1)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 11)
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
     fin = engine.trk_get_state()
     for a, b in zip(fin, ofin):
@@ -167,7 +157,7 @@ def test_consecutive_batches_and_lookahead_planner(gc, orc, engine):
     engine.trk_set_state(states)
     engine.trk_run(3)
     II2, QQ2, _ = engine.trk_fetch()
-    oII2, oQQ2, _, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 3, mode=1)
+    oII2, oQQ2, _, _ = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 3)
     assert np.array_equal(II2, oII2) and np.array_equal(QQ2, oQQ2)
 
 
@@ -181,8 +171,8 @@ def _code_case(case, rng):
         c = np.ones(1023, np.int16)
         c[[5, 6, 400, 1022]] = -1
         return c, 1.023e6 - 1.0, 1000.9, 16370
-    if case == "short_fast":        # 2.5 chips per sample over a 10-chip code: hundreds of periods per round
-        return rng.choice(np.array([-1, 1], np.int16), size=10), 2.5 * F_SF, 3.3, 9000
+    if case == "short_fast":        # 0.7 chips per sample over a 300-chip code: two code periods in the call
+        return rng.choice(np.array([-1, 1], np.int16), size=300), 0.7 * F_SF, 3.3, 850
     if case == "slow":              # 200 samples per chip
         return rng.choice(np.array([-1, 1], np.int16), size=1023), F_SF / 200.0, 77.2531, 16368
     raise ValueError(case)
@@ -204,12 +194,26 @@ def test_correlator_symbol_code_shapes(gc, orc, case, dtype):
     freq = 4.092e6 + 777.0 if dtype == 1 else -2345.6
     L.correlator(data.ctypes.data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s.ctypes.data, 2,
                  II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code.ctypes.data, len(code))
-    oII, oQQ, orc_c, orc_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s, code, 1)
+    oII, oQQ, orc_c, orc_p = orc.correlator(data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s, code)
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
     assert remc.value == orc_c and remp.value == orc_p
-    if case != "short_fast":        # the literal NCO's running fp64 sum drifts over 22500 chips
-        sII, sQQ, _, _ = orc.correlator(data, dtype, 1 / F_SF, n, freq, 1.1, crate, coff, s, code, 0)
-        assert rel_err(II, sII) <= 1e-4 and rel_err(QQ, sQQ) <= 1e-4
+
+
+def test_correlator_symbol_refuses_many_code_periods(gc, orc, capfd):
+    """A call that spans far more code periods than sdrtracking() ever asks for (one, ref src/sdrtrk.c:31-32)
+    needs more NCO pieces than the tables hold: the symbol reports it and leaves the outputs untouched, like
+    the reference's own failure path (ref src/sdrcmn.c:697-702)."""
+    L = gc.lib()
+    rng = np.random.default_rng(8)
+    code = rng.choice(np.array([-1, 1], np.int16), size=10)
+    n = 9000
+    data = rng.integers(-128, 128, size=2 * n, dtype=np.int8)
+    s = np.array([2, 5], np.int32)
+    II, QQ = np.full(5, 7.5), np.full(5, -7.5)
+    remc, remp = C.c_double(1.0), C.c_double(2.0)
+    L.correlator(data.ctypes.data, 2, 1 / F_SF, n, 100.0, 0.0, 2.5 * F_SF, 3.3, s.ctypes.data, 2,
+                 II.ctypes.data, QQ.ctypes.data, C.byref(remc), C.byref(remp), code.ctypes.data, len(code))
+    assert np.all(II == 7.5) and np.all(QQ == -7.5) and remc.value == 1.0 and remp.value == 2.0
 
 
 def test_prefix_and_replica_forms_agree(gc, orc, engine, tmp_path):
@@ -252,9 +256,9 @@ print(json.dumps(dict(II=II.tolist(), QQ=QQ.tolist(), ns=ns.tolist())))
 
 
 def test_planner_chain_long_batch(gc, orc, engine):
-    """400 code periods per channel in one batch: the planner's chained closed forms (code / carrier
-    remainders, currnsamp) must track the oracle's to the last bit over the whole chain -- any one-ulp
-    slip in a remainder would show up in the samples-per-period sequence or the final state."""
+    """400 code periods per channel in one batch: the planner's chained NCO walks (code / carrier
+    remainders, currnsamp) must track the literal loops to the last bit over the whole chain -- any
+    one-ulp slip in a remainder would show up in the samples-per-period sequence or the final state."""
     nepoch = 400
     nsamples = 16368 * (nepoch + 12)
     data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[1, 6, 14, 23, 31, 9, 18, 27],
@@ -268,7 +272,7 @@ def test_planner_chain_long_batch(gc, orc, engine):
     engine.trk_run(nepoch)
     II, QQ, ns = engine.trk_fetch()
     fin = engine.trk_get_state()
-    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch, mode=1)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch)
     assert np.array_equal(ns, ons)
     for a, b in zip(fin, ofin):
         assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
@@ -295,8 +299,54 @@ def test_trk_20msps_period(gc, orc, engine):
     engine.trk_run(5)
     II, QQ, ns = engine.trk_fetch()
     ochs = [orc.make_chan(c.prn, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for c in chans]
-    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 5, mode=1)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 5)
     assert np.array_equal(ns, ons) and ns[:, 1:].min() >= 19999      # (the first period is cut by remcode)
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
     with pytest.raises(gc.GnsscorrError):
         engine.acq_run(12 * 20000)
+
+
+def test_closed_loop_from_acquisition_state(gc, orc, engine, synth):
+    """The flow every channel goes through (ref src/sdrmain.c:264-312): tracking starts from what
+    sdracquisition() leaves (remcode = remcarr = 0, carrfreq on the 200 Hz grid, codefreq = crate, ref
+    src/sdracq.c:51-55) and pll()/dll() move the frequencies after every period (ref src/sdrtrk.c:95-150).
+    40 periods on a 48 dB-Hz signal, host-side loop filters, one trk_run per period: sums, samples per
+    period and state equal to the literal oracle bit for bit."""
+    prns = [3, 11, 22]
+    nper = 48
+    dop, cph = [1234.0, -2750.0, 4100.0], [100.3, 700.9, 13.0]
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in prns}
+    sats = [dict(prn=p, doppler=d, codephase=c, cn0=48.0, phase=0.3 * i) for i, (p, d, c) in enumerate(zip(prns, dop, cph))]
+    sig = synth.make_if(codes, 16368 * nper, f_sf=F_SF, f_if=0.0, dtype=2, sats=sats, seed=31)
+    nsamples = sig.shape[0]
+    engine.ring_create(1, 2, nsamples)
+    engine.ring_push_raw(1, sig, nsamples)
+    chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in prns]
+    engine.set_channels(chans)
+    L = orc.lib()
+    ring = orc.make_ring(sig, nsamples, nsamples)
+    for i, (c, f) in enumerate(zip(chans, (1200.0, -2800.0, 4200.0))):
+        o = orc.make_chan(c.prn, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+        o.acq.acqfreq = f
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = f, c.crate, 0.0, 0.0
+        # code phase of the synthesized signal -> first sample of a code period (what acqcodei gives)
+        buffloc = int(round((1023 - cph[i]) * 16)) % 16368
+        for e in range(40):
+            engine.trk_set_state([dict(carrfreq=o.carrfreq, codefreq=o.codefreq, remcode=o.remcode,
+                                       remcarr=o.remcarr, buffloc=buffloc)], ch0=i)
+            engine.trk_run(1)
+            II, QQ, ns = engine.trk_fetch()
+            st = engine.trk_get_state()[i]
+            L.orc_sdrtracking(C.byref(o), C.byref(ring), buffloc)
+            assert o.flagtrk == 1
+            assert ns[i, 0] == o.currnsamp, (i, e)
+            assert np.array_equal(II[i, 0], np.ctypeslib.as_array(o.II)[:5]), (i, e)
+            assert np.array_equal(QQ[i, 0], np.ctypeslib.as_array(o.QQ)[:5]), (i, e)
+            assert st["remcode"] == o.remcode and st["remcarr"] == o.remcarr, (i, e)
+            L.orc_cumsumcorr(C.byref(o), 1)
+            L.orc_pll(C.byref(o), 0, o.ctime)
+            L.orc_dll(C.byref(o), 0, o.ctime)
+            L.orc_clearcumsumcorr(C.byref(o))
+            buffloc += o.currnsamp
+        # the loops pulled in: prompt power well above the early/late mean by the end
+        assert abs(o.carrfreq - dop[i]) < 150.0

@@ -82,15 +82,11 @@ def test_mixcarr_flavours_and_numpy(orc, dtype, freq, phi0):
     rng = np.random.default_rng(1)
     data = rng.integers(-128, 128, size=n * dtype, dtype=np.int8)
     out = {}
-    for name in ("seq", "cf"):
-        I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
-        f = getattr(orc.lib(), f"orc_mixcarr_{name}")
-        rem = f(data.ctypes.data, dtype, TI, n, freq, phi0, I.ctypes.data, Q.ctypes.data)
-        out[name] = (I.astype(np.int64), Q.astype(np.int64), rem)
+    I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    rem = orc.lib().orc_mixcarr_seq(data.ctypes.data, dtype, TI, n, freq, phi0, I.ctypes.data, Q.ctypes.data)
+    out["seq"] = (I.astype(np.int64), Q.astype(np.int64), rem)
     nI, nQ = _np_mix(data, dtype, TI, n, freq, phi0)
-    assert np.array_equal(out["cf"][0], nI) and np.array_equal(out["cf"][1], nQ)
     assert np.array_equal(out["seq"][0], nI) and np.array_equal(out["seq"][1], nQ)
-    assert abs(out["seq"][2] - out["cf"][2]) < 1e-7
     if freq > 0:
         assert 0 <= out["seq"][2] <= 2 * np.pi + 1e-12
     else:
@@ -105,11 +101,10 @@ def test_rescode_flavours(orc):
         ci = TI * (crate + dc)
         n = 16368
         a = np.zeros(n + 2 * smax, np.int16)
-        b = np.zeros_like(a)
         ra = L.orc_rescode_seq(code.ctypes.data, 1023, coff, smax, ci, n, a.ctypes.data)
-        rb = L.orc_rescode_cf(code.ctypes.data, 1023, coff, smax, ci, n, b.ctypes.data)
-        assert np.array_equal(a, b)
-        assert abs(ra - rb) < 1e-8
+        # returned remainder = code phase after n samples, modulo the code length (the wrap is lazy and the
+        # value has smax*ci subtracted last: it may come back negative or >= clen, ref src/sdrcmn.c:617-620)
+        assert abs(((ra - (coff + n * ci) + 511.5) % 1023) - 511.5) < 1e-6
         # normative closed form: chip = trunc(coff0 + (k + o) * ci) mod clen
         k = np.arange(n + 2 * smax)
         ref = code[np.floor((coff - smax * ci + k * ci) % 1023).astype(int)]
@@ -127,16 +122,15 @@ def test_correlator_against_numpy(orc):
         data = rng.integers(-100, 101, size=n * dtype, dtype=np.int8)
         s = np.array([3, 6], np.int32)
         coff, phi0, cf = 200.3, 1.1, crate + 0.7
-        for mode in (0, 1):
-            II, QQ, remc, remp = orc.correlator(data, dtype, TI, n, freq, phi0, cf, coff, s, code, mode)
-            mI, mQ = _np_mix(data, dtype, TI, n, freq, phi0)
-            ci = TI * cf
-            for t, o in enumerate((0, -3, 3, -6, 6)):
-                k = np.arange(n)
-                chips = code[np.floor((coff + (k + o) * ci) % 1023).astype(int)].astype(np.int64)
-                assert II[t] == np.dot(mI, chips) / 32.0
-                assert QQ[t] == np.dot(mQ, chips) / 32.0
-            assert abs(remc - ((coff + n * ci) % 1023)) < 1e-6
+        II, QQ, remc, remp = orc.correlator(data, dtype, TI, n, freq, phi0, cf, coff, s, code)
+        mI, mQ = _np_mix(data, dtype, TI, n, freq, phi0)
+        ci = TI * cf
+        for t, o in enumerate((0, -3, 3, -6, 6)):
+            k = np.arange(n)
+            chips = code[np.floor((coff + (k + o) * ci) % 1023).astype(int)].astype(np.int64)
+            assert II[t] == np.dot(mI, chips) / 32.0
+            assert QQ[t] == np.dot(mQ, chips) / 32.0
+        assert abs(remc - ((coff + n * ci) % 1023)) < 1e-6
 
 
 def test_cpxconv_equals_time_domain(orc):
@@ -150,17 +144,17 @@ def test_cpxconv_equals_time_domain(orc):
     xc = orc.codespectrum(ch)
     P = np.zeros(3 * n)
     L.orc_pcorrelator(data.ctypes.data, 2, ch.ti, n, freq.ctypes.data, 3, ch.crate, m, xc.ctypes.data,
-                      P.ctypes.data, 0)
+                      P.ctypes.data)
     Ptd = np.zeros(3 * n)
     code = np.ctypeslib.as_array(ch.code).copy()
     L.orc_pcorrelator_td(data.ctypes.data, 2, ch.ti, n, freq.ctypes.data, 3, m, code.ctypes.data, 1023, ch.ci,
-                         100, 140, Ptd.ctypes.data, 0)
+                         100, 140, Ptd.ctypes.data)
     for b in range(3):
         assert rel_err(P[b * n + 100:b * n + 140], Ptd[b * n + 100:b * n + 140]) < 5e-6
     # flagsum accumulates (ref src/sdrcmn.c:244-246)
     P2 = P.copy()
     L.orc_pcorrelator(data.ctypes.data, 2, ch.ti, n, freq.ctypes.data, 3, ch.crate, m, xc.ctypes.data,
-                      P2.ctypes.data, 0)
+                      P2.ctypes.data)
     assert rel_err(P2, 2 * P) < 1e-12
 
 
@@ -207,7 +201,7 @@ def test_tracking_driver_quirks(orc, synth):
         o.II[i], o.QQ[i] = 100.0 + i, 200.0 + i
     o.oldI[4] = -7.0
     L = orc.lib()
-    L.orc_sdrtracking(C.byref(o), C.byref(ring), 31, 0)
+    L.orc_sdrtracking(C.byref(o), C.byref(ring), 31)
     assert o.flagtrk == 1 and o.currnsamp == 16368
     # memcpy of 1+2*corrn*8 = 33 bytes: taps 0..3 copied, tap 4 only its lowest byte
     assert [o.oldI[i] for i in range(4)] == [100.0, 101.0, 102.0, 103.0]
@@ -215,11 +209,11 @@ def test_tracking_driver_quirks(orc, synth):
     buf = np.zeros(2 * 16368, np.int8)
     L.orc_getbuff(C.byref(ring), 31, 16368, 2, buf.ctypes.data)
     code = np.ctypeslib.as_array(o.code).copy()
-    cII, cQQ, _, _ = orc.correlator(buf, 2, o.ti, 16368, 900.0, 0.0, o.crate, 0.0, [3, 6], code, 0)
+    cII, cQQ, _, _ = orc.correlator(buf, 2, o.ti, 16368, 900.0, 0.0, o.crate, 0.0, [3, 6], code)
     assert [o.QQ[i] for i in range(5)] == list(cII)      # trk.QQ <- correlator's II
     assert [o.II[i] for i in range(5)] == list(cQQ)
     # not enough samples buffered: flagtrk stays 0 (ref src/sdrtrk.c:30,50)
-    L.orc_sdrtracking(C.byref(o), C.byref(ring), n - 100, 0)
+    L.orc_sdrtracking(C.byref(o), C.byref(ring), n - 100)
     assert o.flagtrk == 0
 
 
@@ -266,7 +260,7 @@ def test_acquisition_driver_on_synthetic_signal(orc, gc, synth):
     o.xcode = xc.ctypes.data
     P = np.zeros(o.nfreq * o.nsamp)
     it = C.c_int()
-    b = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), P.ctypes.data, 0, C.byref(it))
+    b = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), P.ctypes.data, C.byref(it))
     assert o.flagacq == 1 and it.value == 1
     assert abs(o.acq.acqfreq - (-2345.0)) <= 100.0 + 1e-9
     assert b == nsamples - 11 * 16368 + o.acq.acqcodei
