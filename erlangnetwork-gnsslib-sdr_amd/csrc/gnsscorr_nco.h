@@ -331,3 +331,767 @@ GC_HD int gc_carrier_idx_at(const int *k0, const GcCarSeg *seg, int nseg, int k)
     }
     return (int)((seg[lo].fx + (uint64_t)(int64_t)(k - k0[lo]) * seg[lo].dfx) >> 59);
 }
+
+// ---------------------------------------------------------------------------
+// fast walkers
+// ---------------------------------------------------------------------------
+// The planner chains one walk per (channel, period) and sits on the critical path
+// of a tracking batch; gc_nco_run() costs a division and a dozen bit operations per
+// piece.  For the usual case -- a running sum that grows away from zero, i.e. sum
+// and addend of one sign -- everything that depends only on the addend s and on the
+// binade is tabulated once per frequency: the rounded step d_i = RN_u(s), its
+// reciprocal and the tie flag for the binades 2^(es+2) .. 2^(es+2+GC_NB) (es =
+// exponent of s).  A piece then costs: distance to the top of the binade (exact),
+// quotient by reciprocal multiplication, one exact remainder to settle it.  The loops
+// over the table are written with constant indices so that the table lives in
+// registers.  Anything else -- the first few steps next to zero, a sum that shrinks
+// toward zero, ties that start from an odd multiplier, binades beyond the table --
+// falls through to one gc_nco_run() piece and the fast pass is tried again: both
+// produce exact values, so mixing them is free of consequences.
+#define GC_NB 20
+struct GcNcoFast {
+    double s;
+    double inv_s;               // RN(1/|s|)
+    int    ex0;                 // biased exponent of table entry 0
+    unsigned tie;               // bit i: s lies exactly half way between two grid points of binade i
+    double d[GC_NB];            // RN_u(s), signed
+    double inv[GC_NB];          // 1/|d| (0 when d = 0)
+};
+
+GC_HD void gc_fast_init(GcNcoFast &f, double s)
+{
+    GC_FP_STRICT
+    const uint64_t us = gc_d2u(s);
+    const int es = (int)((us >> 52) & 0x7FF);
+    f.s = s;
+    f.inv_s = 1.0 / fabs(s);
+    f.tie = 0;
+    f.ex0 = 0x7FFFFFF;          // no table: zero, subnormal, inf, nan or exponents out of range
+    const bool ok = es > 60 && es < 0x7FF - GC_NB - 4;
+    if (ok) f.ex0 = es + 2;
+#pragma unroll
+    for (int i = 0; i < GC_NB; i++) {
+        f.d[i] = 0.0;
+        f.inv[i] = 0.0;
+        if (!ok) continue;
+        const int ex = es + 2 + i;
+        const int et = es + 1075 - ex;                  // exponent of t = s/u, < 1023 + 51 by construction
+        double b = 0.0;
+        if (et >= 1023 - 1) {
+            const double t = gc_u2d((us & 0x800FFFFFFFFFFFFFull) | ((uint64_t)et << 52));
+            b = rint(t);
+            if (fabs(t - b) == 0.5) f.tie |= 1u << i;
+        }
+        f.d[i] = ldexp(b, ex - 1075);
+        if (b != 0.0) f.inv[i] = 1.0 / fabs(f.d[i]);
+    }
+}
+
+// one table piece: x in binade ex0 + i, growing.  lim_below: values must stay below it (code: the code
+// length; carrier: +inf).  Returns the run length m <= cap with x + j d exact for j <= m.
+GC_HD int gc_fast_piece(const GcNcoFast &f, int i, double x, int cap, double lim_below)
+{
+    GC_FP_STRICT
+    // (written without branches: on the device this runs on one lane of a wavefront, where a taken
+    // branch costs more than the whole piece)
+    const uint64_t ux = gc_d2u(x);
+    const double top = fabs(gc_u2d(ux | 0x000FFFFFFFFFFFFFull));           // largest magnitude of the binade
+    const double u = gc_u2d((uint64_t)(((ux >> 52) & 0x7FF) - 52) << 52);   // its grid
+    const double lim = lim_below <= top ? lim_below - u : top;              // below lim_below, on the grid
+    const double R = lim - fabs(x);                                         // exact (same binade)
+    const double dabs = fabs(f.d[i]);
+    double q = floor(R * f.inv[i]);
+    const double r = fma(-q, dabs, R);                                      // exact
+    q += r < 0.0 ? -1.0 : (r >= dabs ? 1.0 : 0.0);
+    q = q < 0.0 ? 0.0 : q;
+    const double dc = (double)cap;
+    q = (q > dc || dabs == 0.0) ? dc : q;                                   // d = 0: the sum never moves
+    q = R < 0.0 ? 0.0 : q;
+    return (int)q;
+}
+
+template <class Emit>
+GC_HD double gc_fast_carrier_walk(const GcNcoFast &f, double x, int n, Emit &emit)
+{
+    GC_FP_STRICT
+    const double s = f.s;
+    const bool table = f.ex0 != 0x7FFFFFF;
+    int k = 0;
+    while (k < n) {
+        const int kin = k;
+        // next to zero (fewer than ~4 steps per binade) every sample is its own piece: the reference's
+        // own additions, in a loop of their own
+        while (table && k < n && (x == 0.0 || (int)((gc_d2u(x) >> 52) & 0x7FF) < f.ex0)) {
+            emit(k, x, 0.0, 1);
+            x = x + s;
+            k += 1;
+        }
+        if (k < n && x != 0.0 && (gc_d2u(x) >> 63) == (gc_d2u(s) >> 63)) {
+            const int i0 = (int)((gc_d2u(x) >> 52) & 0x7FF) - f.ex0;
+#pragma unroll
+            for (int i = 0; i < GC_NB; i++) {
+                if (i < i0) continue;
+                const uint64_t ux = gc_d2u(x);
+                if (!(k < n && (int)((ux >> 52) & 0x7FF) == f.ex0 + i)) break;
+                if (!(((f.tie >> i) & 1) && (ux & 1))) {
+                    const int m = gc_fast_piece(f, i, x, n - 1 - k, INFINITY);
+                    emit(k, x, f.d[i], m + 1);
+                    x = fma((double)m, f.d[i], x);
+                    k += m;
+                    x = x + s;
+                    k += 1;
+                }
+            }
+        }
+        if (k != kin) continue;
+        double d;
+        const int64_t m = gc_nco_run(x, s, (int64_t)(n - 1 - k), &d);
+        emit(k, x, d, (int)m + 1);
+        x = fma((double)m, d, x);
+        k += (int)m;
+        x = x + s;
+        k += 1;
+    }
+    return x;
+}
+
+template <class Emit>
+GC_HD double gc_fast_code_walk(const GcNcoFast &f, double c, int len, int nt, Emit &emit)
+{
+    GC_FP_STRICT
+    const double ci = f.s, dlen = (double)len;
+    const bool table = f.ex0 != 0x7FFFFFF && ci > 0.0;
+    int j = 0, w = 0;
+    while (j < nt) {
+        if (c >= dlen) { c = c - dlen; w++; }
+        const int jin = j;
+        while (table && j < nt && c < dlen && (c == 0.0 || (int)((gc_d2u(c) >> 52) & 0x7FF) < f.ex0)) {
+            emit(j, c, 0.0, 1, w);
+            c = c + ci;
+            j += 1;
+        }
+        if (table && j < nt && c > 0.0 && c < dlen) {
+            const int i0 = (int)((gc_d2u(c) >> 52) & 0x7FF) - f.ex0;
+#pragma unroll
+            for (int i = 0; i < GC_NB; i++) {
+                if (i < i0) continue;
+                const uint64_t uc = gc_d2u(c);
+                if (!(j < nt && c < dlen && (int)((uc >> 52) & 0x7FF) == f.ex0 + i)) break;
+                if (!(((f.tie >> i) & 1) && (uc & 1))) {
+                    const int m = gc_fast_piece(f, i, c, nt - 1 - j, dlen);
+                    emit(j, c, f.d[i], m + 1, w);
+                    c = fma((double)m, f.d[i], c);
+                    j += m;
+                    c = c + ci;
+                    j += 1;
+                }
+            }
+        }
+        if (j != jin) continue;
+        double d;
+        int64_t m = gc_nco_run(c, ci, (int64_t)(nt - 1 - j), &d);
+        if (m > 0 && d > 0.0) {
+            const double est = floor((dlen - c) / d);
+            if (est < (double)m) m = est > 0.0 ? (int64_t)est : 0;
+            while (m > 0 && !(fma((double)m, d, c) < dlen)) m--;
+        }
+        emit(j, c, d, (int)m + 1, w);
+        c = fma((double)m, d, c);
+        j += (int)m;
+        c = c + ci;
+        j += 1;
+    }
+    return c;
+}
+
+// prem (ref src/sdrcmn.c:666-668) with the subtraction loop run through a table for the addend -DPI
+// (gc_fast_init(f, -GC_NCO_DPI)): a phase of thousands of radians (a 4 MHz IF over one code period)
+// comes down one binade per piece; the last few subtractions are the reference's own.
+GC_HD double gc_fast_prem(const GcNcoFast &f, double phi)
+{
+    GC_FP_STRICT
+    double p = GC_DDIV(phi * GC_NCO_DPI, GC_NCO_CDIV);
+    if (!(p < 1.0e300)) return p;
+    // table binades start at 2^(ex0 - 1023) = 16 > DPI: inside them every value exceeds DPI, so the loop
+    // condition holds for every step of a piece
+    bool more = (int)((gc_d2u(p) >> 52) & 0x7FF) >= f.ex0 && p > 0.0;      // below 16: the plain loop at the end
+    while (more) {
+        more = false;
+#pragma unroll
+        for (int i = GC_NB - 1; i >= 0; i--) {
+            const uint64_t up = gc_d2u(p);
+            if ((int)((up >> 52) & 0x7FF) == f.ex0 + i && !(up >> 63) && !(((f.tie >> i) & 1) && (up & 1))) {
+                // down to the multiplier 2^52 + 1 of this binade
+                const double lo = gc_u2d((up & 0xFFF0000000000000ull) | 1ull);
+                const double R = p - lo;
+                const double dabs = fabs(f.d[i]);
+                if (R >= dabs && dabs > 0.0) {
+                    double q = floor(R * f.inv[i]);
+                    const double r = fma(-q, dabs, R);
+                    if (r < 0.0) q -= 1.0;
+                    else if (r >= dabs) q += 1.0;
+                    p = fma(q, f.d[i], p);
+                }
+                p = p - GC_NCO_DPI;              // (p > DPI here)
+                more = true;
+            }
+        }
+        if ((int)((gc_d2u(p) >> 52) & 0x7FF) >= f.ex0 + GC_NB) return gc_carrier_prem(phi);   // beyond the table
+    }
+    while (p > GC_NCO_DPI) p = p - GC_NCO_DPI;
+    return p;
+}
+
+// x / b for many x and one b, y = RN(1/b) given: q = RN(x y), r = x - b q (exact by fma), RN(q + r y) is
+// the correctly rounded quotient (Markstein) -- three dependent operations instead of the hardware's
+// division sequence; the planner divides by 2 pi and by the chips-per-sample ratio once per period.
+// (Checked against true division: 2.5e8 random operands for b = 2 pi and for chip-per-sample ratios,
+// no mismatch; tests/test_nco_host.py repeats a sample of it.)
+GC_HD double gc_div_y(double x, double b, double y)
+{
+    GC_FP_STRICT
+    const double q = x * y;
+    const double r = fma(-q, b, x);
+    return fma(r, y, q);
+}
+
+// gc_code_start without its division while -len <= coff - smax*ci < len (the neighbours of -1, 0 and 1
+// are more than an ulp away from the quotient there, so its floor is -1 or 0 by sign alone)
+GC_HD double gc_code_start_fast(double coff, double smaxci, int len)
+{
+    GC_FP_STRICT
+    const double dlen = (double)len;
+    double cs = coff - smaxci;
+    double fl = cs < 0.0 ? -1.0 : 0.0;
+    if (!(cs >= -dlen && cs < dlen)) fl = floor(GC_DDIV(cs, dlen));
+    return cs - fl * dlen;
+}
+
+// ---------------------------------------------------------------------------
+// certified crossings: the planner's form of the walk
+// ---------------------------------------------------------------------------
+// On the device the planner's chain runs on one wavefront per channel and pays ~10 clocks per
+// instruction whatever it does, so what has to be sequential is cut to two additions per binade:
+//
+//   * WHERE the running sum crosses each binade boundary b (the first index k with |x_k| >= b) does
+//     not need the chain.  The exact-arithmetic sum x0 + k s differs from the reference's running
+//     sum by the accumulated rounding, at most E(b) = sum over the binades below b of (steps in the
+//     binade) * ulp/2 <= b (b/|s| + 4) 2^-53.  If x0 + (k-1) s and x0 + k s lie on either side of b
+//     by more than E(b) plus the evaluation error, k is the crossing of the reference's sum too --
+//     for all boundaries at once, one per lane (gc_cert_crossing).  Sums that involve no rounding at
+//     all (a step that is a multiple of the coarsest grid: the nominal chip rate 1/16) are compared
+//     exactly instead.
+//   * WHAT the sum is there does need the chain, but with the crossings known it is one fma (the
+//     steps inside the binade, all equal to RN_u(s)) and one addition (the reference's own, across
+//     the boundary) per binade: gc_cert_chain.
+//
+// A boundary that cannot be certified (the sum passes within ~1e-9 of it: about once in 1e7
+// periods), a tie binade entered on an odd multiplier, or a walk that is not of the usual shape
+// makes the caller fall back to the piece walkers above; every path yields the reference's values.
+#define GC_CERT_FAIL (-1)
+#define GC_CERT_FAR  0x3fffffff     // certified: not reached within n steps
+
+// first k in [1, n] with a0 + k*sabs >= b for the reference's rounded running sum (a0 < b), given
+// mg = 0 when no addition of the walk rounds (then the products below are exact) and the bound of the
+// accumulated rounding otherwise.  inv = RN(1/sabs).
+GC_HD int gc_cert_crossing(double a0, double sabs, double inv, double b, double mg, int n)
+{
+    GC_FP_STRICT
+    double k = ceil((b - a0) * inv);
+    k = k < 1.0 ? 1.0 : k;
+    const double dn = (double)n;
+    if (k > dn + 1.0) k = dn + 1.0;
+    double lo = fma(k - 1.0, sabs, a0), hi = fma(k, sabs, a0);
+    // the quotient estimate may be one off
+    const bool down = lo >= b, up = hi < b;
+    k = down ? k - 1.0 : (up ? k + 1.0 : k);
+    const double lo2 = down ? fma(k - 1.0, sabs, a0) : (up ? hi : lo);
+    const double hi2 = down ? lo : (up ? fma(k, sabs, a0) : hi);
+    lo = lo2;
+    hi = hi2;
+    if (k > dn) {           // not within n steps, if the last sum stays clear of b
+        const double last = fma(dn, sabs, a0);
+        return last < b - mg ? GC_CERT_FAR : GC_CERT_FAIL;
+    }
+    if (k < 1.0) return GC_CERT_FAIL;
+    const bool ok = mg == 0.0 ? (lo < b && hi >= b) : (lo < b - mg && hi >= b + mg);
+    return ok ? (int)k : GC_CERT_FAIL;
+}
+
+// rounding accumulated by the reference's sum below b (generous), plus the error of evaluating
+// a0 + k*sabs once
+GC_HD double gc_cert_margin(double b, double inv)
+{
+    GC_FP_STRICT
+    return b * (b * inv + 8.0) * 1.1102230246251565e-16;       // 2^-53
+}
+
+// no addition of a walk from x0 with step s up to magnitude `top` rounds: x0 and s are multiples of
+// ulp(top)
+GC_HD bool gc_cert_exact(double x0, double s, double top)
+{
+    const int et = (int)((gc_d2u(top) >> 52) & 0x7FF);
+    if (et < 64) return false;
+    const double sc = gc_u2d((uint64_t)(2046 - (et - 52)) << 52);           // 1/ulp(top)
+    const double a = x0 * sc, b = s * sc;
+    return a == rint(a) && b == rint(b) && fabs(a) < 9.0e15 && fabs(b) < 9.0e15;
+}
+
+// The chain: from x (sample index k, |x| inside table binade i0) over the table binades to index n.
+// K[i] (i > i0) = certified index of the first sample in binade i or above (relative to index 0 of
+// the same x0 the crossings were computed from); Klim/blim: the same for the walk's upper limit
+// (code: the code length, carrier: none = GC_CERT_FAR), which lies in binade ilim.
+// On return *kout = index reached: n (then the value is x_n), or the index of the first sample at
+// or above the limit (then the value is that sample's).  Returns false when a tie binade was
+// entered on an odd multiplier (caller falls back); values are exact otherwise.
+GC_HD bool gc_cert_chain(const GcNcoFast &f, double *px, int *pk, int n, int i0, const int *K, int ilim, int Klim)
+{
+    GC_FP_STRICT
+    double x = *px;
+    int k = *pk;
+    const double s = f.s;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < GC_NB; i++) {
+        if (i < i0 || i > ilim || k >= n) continue;
+        // last index inside this binade: before the next boundary, before the limit, before n
+        int last = i + 1 < GC_NB ? K[i + 1] - 1 : n - 1;
+        if (i == ilim) last = Klim - 1;
+        if (last > n - 1) last = n - 1;
+        int m = last - k;
+        if (m < 0) { ok = false; continue; }
+        if (((f.tie >> i) & 1) && (gc_d2u(x) & 1) && m > 0) {
+            // a tie binade entered on an odd multiplier: this one step rounds the other way (to the even
+            // neighbour); from there on the step is f.d[i]
+            x = x + s;
+            m -= 1;
+        }
+        x = fma((double)m, f.d[i], x);
+        k = last;
+        x = x + s;
+        k += 1;
+    }
+    *px = x;
+    *pk = k;
+    return ok;
+}
+
+// Crossings of one growing stretch, computed "per lane": boundary index i in (i0, GC_NB) is the bottom
+// of table binade i, boundary GC_NB is the walk's limit (the code length; carrier: none).  On the host
+// this is a loop, on the device lane i computes K[i] (gnsscorr_trk.hip) -- same function per boundary.
+struct GcCertCtx {
+    double a0, sabs, inv;   // |x0|, |s|, RN(1/|s|)
+    int    n;               // steps available
+    bool   exact;           // no addition of the stretch rounds
+    int    ex0;
+};
+
+GC_HD int gc_cert_lane(const GcCertCtx &c, int i, double lim)
+{
+    // boundary value: bottom of table binade i, or the limit for i == GC_NB
+    const double b = i < GC_NB ? gc_u2d((uint64_t)(c.ex0 + i) << 52) : lim;
+    if (!(b > c.a0)) return 0;
+    if (!(b < 1.0e300)) return GC_CERT_FAR;
+    return gc_cert_crossing(c.a0, c.sabs, c.inv, b, c.exact ? 0.0 : gc_cert_margin(b, c.inv), c.n);
+}
+
+// One growing stretch through the table by certified crossings: x at index k (same sign as s, inside
+// the table, below lim) -> index n or the first sample at/above lim.  gc_cert_setup checks the shape
+// and prepares the per-boundary context; then one gc_cert_lane per boundary (host: a loop, device: one
+// lane each); then gc_cert_chain.  false: not done (caller falls back to the piece walkers).
+GC_HD bool gc_cert_setup(const GcNcoFast &f, double x, int k, int n, double lim, GcCertCtx *c, int *pi0, int *pilim)
+{
+    GC_FP_STRICT
+    const int ex = (int)((gc_d2u(x) >> 52) & 0x7FF);
+    const int i0 = ex - f.ex0;
+    if (f.ex0 == 0x7FFFFFF || i0 < 0 || i0 >= GC_NB || !(fabs(x) < lim)) return false;
+    if ((gc_d2u(x) >> 63) != (gc_d2u(f.s) >> 63)) return false;
+    c->a0 = fabs(x);
+    c->sabs = fabs(f.s);
+    c->inv = f.inv_s;
+    c->n = n - k;
+    c->ex0 = f.ex0;
+    int ilim = GC_NB - 1;
+    double reach = fma((double)c->n, c->sabs, c->a0);
+    if (lim < 1.0e300) {
+        // binade of the largest value below the limit
+        const double below = gc_u2d(gc_d2u(lim) - 1);
+        ilim = (int)((gc_d2u(below) >> 52) & 0x7FF) - f.ex0;
+        if (ilim < i0 || ilim >= GC_NB) return false;
+        // the sample that reaches the limit must still be inside binade ilim (lim + |s| below its top)
+        if (!(lim + c->sabs < gc_u2d((uint64_t)(f.ex0 + ilim + 1) << 52))) return false;
+        if (reach > lim + c->sabs) reach = lim + c->sabs;
+    } else if (!(reach < gc_u2d((uint64_t)(f.ex0 + GC_NB) << 52))) {
+        return false;                       // runs off the table
+    }
+    c->exact = gc_cert_exact(x, f.s, reach);
+    *pi0 = i0;
+    *pilim = ilim;
+    return true;
+}
+
+GC_HD bool gc_cert_stretch(const GcNcoFast &f, double *px, int *pk, int n, double lim, int *K)
+{
+    GcCertCtx c;
+    int i0, ilim;
+    if (!gc_cert_setup(f, *px, *pk, n, lim, &c, &i0, &ilim)) return false;
+    for (int i = i0 + 1; i <= GC_NB; i++) {     // (device: one lane each, gnsscorr_trk.hip)
+        K[i] = (i <= ilim || i == GC_NB) ? gc_cert_lane(c, i, lim) : GC_CERT_FAR;
+        if (K[i] == GC_CERT_FAIL) return false;
+    }
+    double y = *px;
+    int k = 0;
+    if (!gc_cert_chain(f, &y, &k, c.n, i0, K, ilim, K[GC_NB])) return false;
+    *px = y;
+    *pk += k;
+    return true;
+}
+
+// The planner's code walk (end value only): literal steps next to zero, certified stretches through the
+// table, wraps in between; false when a stretch could not be certified (caller: gc_fast_code_walk).
+GC_HD bool gc_plan_code_walk(const GcNcoFast &f, double c, int len, int nt, int *K, double *cend)
+{
+    GC_FP_STRICT
+    const double ci = f.s, dlen = (double)len;
+    if (f.ex0 == 0x7FFFFFF || !(ci > 0.0)) return false;
+    int j = 0;
+    while (j < nt) {
+        if (c >= dlen) c = c - dlen;
+        while (j < nt && c < dlen && (c == 0.0 || (int)((gc_d2u(c) >> 52) & 0x7FF) < f.ex0)) {
+            c = c + ci;
+            j += 1;
+        }
+        if (j >= nt) break;
+        if (c >= dlen) continue;
+        if (!(c > 0.0) || !gc_cert_stretch(f, &c, &j, nt, dlen, K)) return false;
+    }
+    *cend = c;
+    return true;
+}
+
+// A sum far above its addend (a negative carrier phase is never wrapped, ref src/sdrcmn.c:667: after a
+// fraction of a second it is thousands of LUT steps while the step stays ~0.01) spends the whole period
+// inside one binade: n equal steps d = RN_u(s), if the last one stays below the top of the binade.
+GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn)
+{
+    GC_FP_STRICT
+    const uint64_t ux = gc_d2u(x), us = gc_d2u(s);
+    const int ex = (int)((ux >> 52) & 0x7FF), es = (int)((us >> 52) & 0x7FF);
+    if (ex == 0 || ex == 0x7FF || es == 0 || es == 0x7FF || (ux >> 63) != (us >> 63)) return false;
+    const int et = es + 1075 - ex;
+    if (et >= 1023 + 51) return false;
+    double b = 0.0;
+    if (et >= 1023 - 1) {
+        const double t = gc_u2d((us & 0x800FFFFFFFFFFFFFull) | ((uint64_t)et << 52));
+        b = rint(t);
+        if (fabs(t - b) == 0.5 && (ux & 1)) return false;      // tie from an odd multiplier
+    }
+    const double d = ldexp(b, ex - 1075);
+    const double y = fma((double)n, d, x);
+    const double top = fabs(gc_u2d(ux | 0x000FFFFFFFFFFFFFull));
+    if (!(fabs(y) <= top)) return false;
+    *xn = y;
+    return true;
+}
+
+// The planner's carrier walk (value after n additions); false: caller uses gc_fast_carrier_walk.
+GC_HD bool gc_plan_carrier_walk(const GcNcoFast &f, double x, int n, int *K, double *xn)
+{
+    GC_FP_STRICT
+    if (f.ex0 == 0x7FFFFFF) return false;
+    if ((int)((gc_d2u(x) >> 52) & 0x7FF) >= f.ex0 + GC_NB) return gc_one_binade_walk(x, f.s, n, xn);
+    int k = 0;
+    while (k < n && (x == 0.0 || (int)((gc_d2u(x) >> 52) & 0x7FF) < f.ex0)) {
+        x = x + f.s;
+        k += 1;
+    }
+    if (k < n && !gc_cert_stretch(f, &x, &k, n, INFINITY, K)) return false;
+    if (k != n) return false;
+    *xn = x;
+    return true;
+}
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------
+// device planner: one wavefront per channel, lane i = binade boundary i
+// ---------------------------------------------------------------------------
+// device form of gc_cert_stretch (gnsscorr_nco.h): the crossings one per lane.  Ks: LDS, GC_NB + 2 ints.
+__device__ __forceinline__ bool cert_stretch_dev(const GcNcoFast &f, double *px, int *pk, int n, double lim, int *Ks,
+                                                 int lane)
+{
+    GcCertCtx c;
+    int i0, ilim;
+    if (!gc_cert_setup(f, *px, *pk, n, lim, &c, &i0, &ilim)) return false;        // (wave-uniform)
+    int Kl = GC_CERT_FAR;
+    if (lane > i0 && lane <= GC_NB && (lane <= ilim || lane == GC_NB)) Kl = gc_cert_lane(c, lane, lim);
+    if (__any(Kl == GC_CERT_FAIL)) return false;
+    if (lane <= GC_NB) Ks[lane] = Kl;
+    __syncthreads();
+    double y = *px;
+    int k = 0;
+    const bool ok = gc_cert_chain(f, &y, &k, c.n, i0, Ks, ilim, Ks[GC_NB]);
+    __syncthreads();                                                               // before Ks is rewritten
+    if (!ok) return false;
+    *px = y;
+    *pk += k;
+    return true;
+}
+
+// gc_plan_code_walk / gc_plan_carrier_walk with the lanes at work
+__device__ __forceinline__ bool plan_code_dev(const GcNcoFast &f, double c, int len, int nt, int *Ks, int lane, double *cend)
+{
+    const double ci = f.s, dlen = (double)len;
+    if (f.ex0 == 0x7FFFFFF || !(ci > 0.0)) return false;
+    int j = 0;
+    while (j < nt) {
+        if (c >= dlen) c = __dsub_rn(c, dlen);
+        while (j < nt && c < dlen && (c == 0.0 || (int)((gc_d2u(c) >> 52) & 0x7FF) < f.ex0)) {
+            c = __dadd_rn(c, ci);
+            j += 1;
+        }
+        if (j >= nt) break;
+        if (c >= dlen) continue;
+        if (!(c > 0.0) || !cert_stretch_dev(f, &c, &j, nt, dlen, Ks, lane)) return false;
+    }
+    *cend = c;
+    return true;
+}
+
+__device__ __forceinline__ bool plan_carrier_dev(const GcNcoFast &f, double x, int n, int *Ks, int lane, double *xn)
+{
+    if (f.ex0 == 0x7FFFFFF) return false;
+    if ((int)((gc_d2u(x) >> 52) & 0x7FF) >= f.ex0 + GC_NB) return gc_one_binade_walk(x, f.s, n, xn);
+    int k = 0;
+    while (k < n && (x == 0.0 || (int)((gc_d2u(x) >> 52) & 0x7FF) < f.ex0)) {
+        x = __dadd_rn(x, f.s);
+        k += 1;
+    }
+    if (k < n && !cert_stretch_dev(f, &x, &k, n, INFINITY, Ks, lane)) return false;
+    if (k != n) return false;
+    *xn = x;
+    return true;
+}
+
+#endif
+
+// ---------------------------------------------------------------------------
+// the planner's period step, specialised to the shape a tracked channel has
+// ---------------------------------------------------------------------------
+// Code NCO of one period of a tracked channel (ref src/sdrcmn.c:613-620 as driven by
+// src/sdrtrk.c:31-43): the replica starts 2*smax samples before the end of the previous code period,
+// i.e. in the binade that holds the code length ("head": a few equal steps up to the wrap), wraps,
+// climbs through every binade from ~4 ci to the code length again ("climb"), wraps a second time and
+// ends after another ~2*smax samples next to zero ("tail").  gc_code_period() walks exactly that:
+//   head   one exact quotient (the values are c0 + j d_top),
+//   climb  crossings of the binade boundaries certified one per lane (`fill`), then a chain of one fma
+//          and one addition per binade with nothing else on its dependency path,
+//   tail   the reference's own additions.
+// Anything that does not fit (period not ending in the tail, first sample outside the top binade, a
+// crossing that cannot be certified, ...) returns false and the caller takes the general walkers.
+struct GcCodePlan {
+    GcNcoFast f;            // table for the addend ci
+    double dlen;            // code length
+    double limtop;          // largest value below dlen on its binade's grid
+    double smaxci;          // smax*ci (ref :613)
+    int    itop;            // table binade that holds limtop
+    bool   exact;           // ci is a multiple of ulp(dlen): no addition of the climb rounds
+    bool   ok;              // the table covers the code (else: general walkers only)
+};
+
+GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax)
+{
+    GC_FP_STRICT
+    gc_fast_init(P.f, ci);
+    P.dlen = (double)len;
+    P.smaxci = (double)smax * ci;
+    P.limtop = gc_u2d(gc_d2u(P.dlen) - 1);
+    P.itop = (int)((gc_d2u(P.limtop) >> 52) & 0x7FF) - P.f.ex0;
+    P.ok = P.f.ex0 != 0x7FFFFFF && ci > 0.0 && P.itop >= 1 && P.itop < GC_NB &&
+           P.dlen + ci < gc_u2d((uint64_t)(P.f.ex0 + P.itop + 1) << 52) && !((P.f.tie >> P.itop) & 1);
+    P.exact = P.ok && gc_cert_exact(P.limtop, ci, P.dlen);
+}
+
+// fill(K, ctx, i0, itop, lim): K[i] = certified crossing of boundary i (i0 < i <= itop: bottom of table
+// binade i; i == GC_NB: lim) relative to ctx.a0 -- gc_cert_lane per boundary; returns false on any
+// GC_CERT_FAIL.  (host: GcFillLoop below; device: one lane per boundary + readlane)
+struct GcFillLoop {
+    GC_HDM bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
+    {
+        for (int i = i0 + 1; i <= GC_NB; i++) {
+            K[i] = (i <= itop || i == GC_NB) ? gc_cert_lane(c, i, lim) : GC_CERT_FAR;
+            if (K[i] == GC_CERT_FAIL) return false;
+        }
+        return true;
+    }
+};
+
+template <class Fill>
+GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out)
+{
+    GC_FP_STRICT
+    if (!P.ok) return false;
+    const GcNcoFast &f = P.f;
+    const double ci = f.s, dlen = P.dlen;
+    // ---- start value (ref :613-614) and head: c0 + j d_top < len for j <= q
+    double cs = remcode - P.smaxci;
+    const double fl = cs < 0.0 ? -1.0 : 0.0;
+    if (!(cs >= -dlen && cs < dlen)) return false;
+    const double c0 = cs - fl * dlen;
+    if ((int)((gc_d2u(c0) >> 52) & 0x7FF) != f.ex0 + P.itop || !(c0 < dlen)) return false;
+    const double dtop = f.d[P.itop < GC_NB ? P.itop : 0];
+    double y;
+    int j;
+    {
+        const double R = P.limtop - c0;
+        double q = floor(R * f.inv[P.itop < GC_NB ? P.itop : 0]);
+        const double r = fma(-q, dtop, R);
+        q += r < 0.0 ? -1.0 : (r >= dtop ? 1.0 : 0.0);
+        if (!(q >= 0.0 && q < (double)(nt - 2))) return false;
+        y = fma(q + 1.0, dtop, c0) - dlen;          // first sample at or above len, wrapped (exact)
+        j = (int)q + 1;
+    }
+    // ---- next to zero: the reference's own additions up to the table
+    const double b0 = gc_u2d((uint64_t)f.ex0 << 52);
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const bool lit = y < b0;
+        const double yl = y + ci;
+        y = lit ? yl : y;
+        j += lit ? 1 : 0;
+    }
+    if (!(y >= b0) || j >= nt - 2) return false;
+    // ---- climb: crossings (one boundary per lane), then the chain
+    GcCertCtx c;
+    c.a0 = y;
+    c.sabs = ci;
+    c.inv = f.inv_s;
+    c.n = nt - j;
+    c.exact = P.exact;
+    c.ex0 = f.ex0;
+    const int i0 = (int)((gc_d2u(y) >> 52) & 0x7FF) - f.ex0;
+    if (i0 < 0 || i0 > 1) return false;
+    int K[GC_NB + 1];
+    if (!fill(K, c, i0, P.itop, dlen)) return false;
+    int k = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < GC_NB; i++) {
+        if (i < i0 || i > P.itop) continue;
+        const int Kn = i == P.itop ? K[GC_NB] : K[i + 1];
+        int last = Kn - 1;
+        last = last > c.n - 1 ? c.n - 1 : last;
+        int m = last - k;
+        ok = ok && m >= 0;
+        if ((f.tie >> i) & 1) {                     // (at most one table binade: a uniform branch)
+            const bool odd = (gc_d2u(y) & 1) && m > 0;
+            const double yl = y + ci;
+            y = odd ? yl : y;
+            m -= odd ? 1 : 0;
+        }
+        y = fma((double)m, f.d[i], y);
+        y = y + ci;
+        k = last + 1;
+    }
+    j += k;
+    if (!ok || j >= nt || !(y >= dlen)) return false;       // (the period must end in the tail)
+    // ---- second wrap and tail
+    y = y - dlen;
+    for (int t = nt - j; t > 0; t--) y = y + ci;
+    *remcode_out = y - P.smaxci;
+    return true;
+}
+
+// Carrier NCO of one period (ref src/sdrcmn.c:649-668): phase remainder in, phase remainder out.
+struct GcCarPlan {
+    GcNcoFast f;            // table for the addend ps
+    GcNcoFast fprem;        // table for -DPI (the remainder loop of a phase of thousands of radians)
+    double ydpi;            // RN(1/DPI)
+};
+
+GC_HD void gc_car_plan_init(GcCarPlan &P, double ps)
+{
+    GC_FP_STRICT
+    gc_fast_init(P.f, ps);
+    gc_fast_init(P.fprem, -GC_NCO_DPI);
+    P.ydpi = 1.0 / GC_NCO_DPI;
+}
+
+template <class Fill>
+GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fill, double *remcarr_out)
+{
+    GC_FP_STRICT
+    const GcNcoFast &f = P.f;
+    if (f.ex0 == 0x7FFFFFF || n < 1) return false;
+    const double s = f.s;
+    double x = gc_div_y(remcarr * GC_NCO_CDIV, GC_NCO_DPI, P.ydpi);      // ref :649
+    int k = 0;
+    bool done = false;
+    if ((int)((gc_d2u(x) >> 52) & 0x7FF) >= f.ex0 + GC_NB) {
+        if (!gc_one_binade_walk(x, s, n, &x)) return false;
+        done = true;
+    }
+    if (!done) {
+        // next to zero: the reference's own additions (a channel fresh out of acquisition starts at phase 0)
+        for (int t = 0; t < 8 && k < n && (x == 0.0 || (int)((gc_d2u(x) >> 52) & 0x7FF) < f.ex0); t++) {
+            x = x + s;
+            k += 1;
+        }
+        if (k < n) {
+            const int i0 = (int)((gc_d2u(x) >> 52) & 0x7FF) - f.ex0;
+            if (i0 < 0 || i0 >= GC_NB || (gc_d2u(x) >> 63) != (gc_d2u(s) >> 63)) return false;
+            GcCertCtx c;
+            c.a0 = fabs(x);
+            c.sabs = fabs(s);
+            c.inv = f.inv_s;
+            c.n = n - k;
+            c.exact = false;
+            c.ex0 = f.ex0;
+            if (!(fma((double)c.n, c.sabs, c.a0) < gc_u2d((uint64_t)(f.ex0 + GC_NB) << 52))) return false;
+            int K[GC_NB + 1];
+            if (!fill(K, c, i0, GC_NB - 1, INFINITY)) return false;
+            int kk = 0;
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < GC_NB; i++) {
+                if (i < i0 || kk >= c.n) continue;
+                int last = (i + 1 < GC_NB ? K[i + 1] : GC_CERT_FAR) - 1;
+                last = last > c.n - 1 ? c.n - 1 : last;
+                int m = last - kk;
+                ok = ok && m >= 0;
+                if ((f.tie >> i) & 1) {
+                    const bool odd = (gc_d2u(x) & 1) && m > 0;
+                    const double xl = x + s;
+                    x = odd ? xl : x;
+                    m -= odd ? 1 : 0;
+                }
+                x = fma((double)m, f.d[i], x);
+                x = x + s;
+                kk = last + 1;
+            }
+            if (!ok || kk != c.n) return false;
+        }
+    }
+    // phase remainder (ref :666-668)
+    double p = x * GC_NCO_DPI * (1.0 / GC_NCO_CDIV);        // (/32: an exact scaling)
+    if (!(p < 1.0e300)) { *remcarr_out = p; return true; }
+    if ((int)((gc_d2u(p) >> 52) & 0x7FF) >= P.fprem.ex0 && p > 0.0) p = gc_fast_prem(P.fprem, x);
+    else while (p > GC_NCO_DPI) p = p - GC_NCO_DPI;
+    *remcarr_out = p;
+    return true;
+}
+
+#if defined(__HIPCC__)
+// crossings one boundary per lane, handed to every lane by readlane (wave-uniform afterwards)
+struct GcFillLanes {
+    int lane;
+    __device__ bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
+    {
+        int Kl = GC_CERT_FAR;
+        if (lane > i0 && lane <= GC_NB && (lane <= itop || lane == GC_NB)) Kl = gc_cert_lane(c, lane, lim);
+        if (__any(Kl == GC_CERT_FAIL)) return false;
+#pragma unroll
+        for (int i = 0; i <= GC_NB; i++) K[i] = __builtin_amdgcn_readlane(Kl, i);
+        return true;
+    }
+};
+#endif

@@ -29,15 +29,22 @@ namespace {
 // NCO chain of sdrtracking() (ref src/sdrtrk.c:31-43): the reference's running
 // fp64 sums walked piece by piece (gnsscorr_nco.h), bit for bit
 // ---------------------------------------------------------------------------
-// one channel per wavefront (lane 0 works): the chain of a channel is sequential in its periods,
-// the channels run side by side on different compute units
+// One channel per wavefront: the chain of a channel is sequential in its periods, the channels run side
+// by side on different compute units.  Per period the lanes compute, one binade boundary each, where the
+// running sums cross it (certified against the accumulated rounding, gnsscorr_nco.h); what is left
+// to the sequential chain is one fma and one addition per binade.
+
 __global__ __launch_bounds__(64) void trk_plan_kernel(const GcChan *__restrict__ chan,
                                                       const GcTrkState *__restrict__ state_in,
                                                       GcTrkState *__restrict__ state_out,
                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch)
 {
-    const int ch = blockIdx.x;
-    if (ch >= nch || threadIdx.x != 0) return;
+    __shared__ int Ks[GC_NB + 2];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= nch) return;
+    // the chain is latency bound and shares its SIMD with correlator wavefronts of the batch before:
+    // let it issue first
+    __builtin_amdgcn_s_setprio(3);
     const GcChan c = chan[ch];
     GcTrkState s = state_in[ch];
     const double ci = __dmul_rn(c.ti, s.codefreq);          // ti*crate, ref src/sdrcmn.c:709
@@ -51,23 +58,52 @@ __global__ __launch_bounds__(64) void trk_plan_kernel(const GcChan *__restrict__
     p.pad = 0;
     GcTrkPlan *out = plan + (size_t)ch * nepoch;
     GcNoEmit ne;
+    // per-binade constants of the addends: the frequencies are held over the batch
+    GcNcoFast fcar, fcode, fprem;
+    gc_fast_init(fcar, ps);
+    gc_fast_init(fcode, ci);
+    gc_fast_init(fprem, -GC_NCO_DPI);
+    // ... and the shape-specialised period steps built on them
+    GcCodePlan PC;
+    GcCarPlan PK;
+    gc_code_plan_init(PC, ci, c.clen, c.smax);
+    gc_car_plan_init(PK, ps);
+    GcFillLanes fill{lane};
+    const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
+    const double smaxci = __dmul_rn((double)c.smax, ci);
+    const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
     for (int e = 0; e < nepoch; e++) {
-        const double q = __ddiv_rn(__dsub_rn(dlen, s.remcode), spc);        // ref src/sdrtrk.c:31-32
+        const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
+        const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
         const int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
         p.buffloc = s.buffloc;
         p.coff = s.remcode;
         p.phi0 = s.remcarr;
         p.n = n;
-        out[e] = p;
+        if (lane == 0) out[e] = p;
         if (n > 0 && n <= (1 << 24)) {
-            s.remcarr = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(s.remcarr), ps, n, ne));
-            if (code_ok)
-                s.remcode = gc_code_rem(gc_code_walk(gc_code_start(s.remcode, c.smax, ci, c.clen), ci, c.clen,
-                                                     n + 2 * c.smax, ne), c.smax, ci);
+            double rp, rc;
+            if (gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
+                s.remcarr = rp;
+            } else {                // any other shape: the general walkers
+                const double phis = gc_div_y(__dmul_rn(s.remcarr, GC_NCO_CDIV), GC_NCO_DPI, ydpi);     // ref src/sdrcmn.c:649
+                double xn;
+                if (!plan_carrier_dev(fcar, phis, n, Ks, lane, &xn)) xn = gc_fast_carrier_walk(fcar, phis, n, ne);
+                s.remcarr = gc_fast_prem(fprem, xn);
+            }
+            if (code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
+                s.remcode = rc;
+            } else if (code_ok) {
+                const double c0 = gc_code_start_fast(s.remcode, smaxci, c.clen);
+                double cend;
+                if (!plan_code_dev(fcode, c0, c.clen, n + 2 * c.smax, Ks, lane, &cend))
+                    cend = gc_fast_code_walk(fcode, c0, c.clen, n + 2 * c.smax, ne);
+                s.remcode = __dsub_rn(cend, smaxci);
+            }
         }
         s.buffloc += (uint64_t)(int64_t)n;
     }
-    state_out[ch] = s;
+    if (lane == 0) state_out[ch] = s;
 }
 
 // rounds per workgroup of the prefix-sum correlator: a whole period when it fits GC_MAXR rounds
@@ -117,9 +153,14 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
         return;
     }
     GcCarTable ct{sg->carK0, sg->car, GC_NCAR, 0, 0};
-    gc_carrier_walk(gc_carrier_phis(p.phi0), gc_carrier_ps(p.carrfreq, c.ti), p.n, ct);
     GcCodeTable dt{sg->code, GC_NCODE, 0, 0};
-    gc_code_walk(gc_code_start(p.coff, c.smax, ci, c.clen), ci, c.clen, u.nt, dt);
+    {
+        GcNcoFast f;
+        gc_fast_init(f, gc_carrier_ps(p.carrfreq, c.ti));
+        gc_fast_carrier_walk(f, gc_carrier_phis(p.phi0), p.n, ct);
+        gc_fast_init(f, ci);
+        gc_fast_code_walk(f, gc_code_start(p.coff, c.smax, ci, c.clen), c.clen, u.nt, dt);
+    }
     u.ncar = ct.n;
     u.ncode = dt.n;
     if (ct.overflow || dt.overflow) {

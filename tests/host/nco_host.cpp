@@ -34,6 +34,100 @@ int nco_code(int len, double coff, int smax, double ci, int n, int cap, int *chi
     return t.n;
 }
 
+// the same through the tabulated fast walkers (what the device planner and expansion run)
+int nco_carrier_fast(double phi0, double freq, double ti, int n, int cap, int *idx, double *prem)
+{
+    int k0[256];
+    GcCarSeg seg[256];
+    if (cap > 256) cap = 256;
+    GcCarTable t{k0, seg, cap, 0, 0};
+    GcNcoFast f;
+    gc_fast_init(f, gc_carrier_ps(freq, ti));
+    const double xn = gc_fast_carrier_walk(f, gc_carrier_phis(phi0), n, t);
+    GcNcoFast fp;
+    gc_fast_init(fp, -GC_NCO_DPI);
+    *prem = gc_fast_prem(fp, xn);
+    if (t.overflow) return -1;
+    for (int k = 0; k < n; k++) idx[k] = gc_carrier_idx_at(k0, seg, t.n, k);
+    return t.n;
+}
+
+int nco_code_fast(int len, double coff, int smax, double ci, int n, int cap, int *chip, double *rem)
+{
+    GcCodeSeg seg[256];
+    if (cap > 256) cap = 256;
+    GcCodeTable t{seg, cap, 0, 0};
+    GcNcoFast f;
+    gc_fast_init(f, ci);
+    const int nt = n + 2 * smax;
+    const double cend = gc_fast_code_walk(f, gc_code_start(coff, smax, ci, len), len, nt, t);
+    *rem = gc_code_rem(cend, smax, ci);
+    if (t.overflow) return -1;
+    for (int j = 0; j < nt; j++) chip[j] = gc_code_chip_at(seg, t.n, j, nullptr);
+    return t.n;
+}
+
+// the planner's chain step exactly as trk_plan_kernel writes it (reciprocal divisions, fast start)
+void nco_chain_fast(double phi0, double freq, double ti, double f_sf, double codefreq, int len, double coff, int smax,
+                    int *n_out, double *prem, double *rem)
+{
+    const double ci = ti * codefreq, spc = codefreq / f_sf, ps = gc_carrier_ps(freq, ti);
+    GcNcoFast fcar, fcode, fprem;
+    gc_fast_init(fcar, ps);
+    gc_fast_init(fcode, ci);
+    gc_fast_init(fprem, -GC_NCO_DPI);
+    const double yspc = 1.0 / spc, ydpi = 1.0 / GC_NCO_DPI, smaxci = (double)smax * ci;
+    const int n = (int)gc_div_y((double)len - coff, spc, yspc);
+    GcNoEmit ne;
+    const double phis = gc_div_y(phi0 * GC_NCO_CDIV, GC_NCO_DPI, ydpi);
+    *prem = gc_fast_prem(fprem, gc_fast_carrier_walk(fcar, phis, n, ne));
+    *rem = gc_fast_code_walk(fcode, gc_code_start_fast(coff, smaxci, len), len, n + 2 * smax, ne) - smaxci;
+    *n_out = n;
+}
+
+// the certified-crossing planner path; *used = 1 when the certified path produced the values (else fallback)
+void nco_chain_cert(double phi0, double freq, double ti, double f_sf, double codefreq, int len, double coff, int smax,
+                    int *n_out, double *prem, double *rem, int *used)
+{
+    const double ci = ti * codefreq, spc = codefreq / f_sf, ps = gc_carrier_ps(freq, ti);
+    GcNcoFast fcar, fcode, fprem;
+    gc_fast_init(fcar, ps);
+    gc_fast_init(fcode, ci);
+    gc_fast_init(fprem, -GC_NCO_DPI);
+    const double yspc = 1.0 / spc, ydpi = 1.0 / GC_NCO_DPI, smaxci = (double)smax * ci;
+    const int n = (int)gc_div_y((double)len - coff, spc, yspc);
+    GcNoEmit ne;
+    int K[GC_NB + 2];
+    const double phis = gc_div_y(phi0 * GC_NCO_CDIV, GC_NCO_DPI, ydpi);
+    double xn, cend;
+    *used = 0;
+    if (gc_plan_carrier_walk(fcar, phis, n, K, &xn)) *used |= 1;
+    else xn = gc_fast_carrier_walk(fcar, phis, n, ne);
+    *prem = gc_fast_prem(fprem, xn);
+    const double c0 = gc_code_start_fast(coff, smaxci, len);
+    if (gc_plan_code_walk(fcode, c0, len, n + 2 * smax, K, &cend)) *used |= 2;
+    else cend = gc_fast_code_walk(fcode, c0, len, n + 2 * smax, ne);
+    *rem = cend - smaxci;
+    *n_out = n;
+}
+
+// the shape-specialised code period step (device: trk_plan_kernel); returns 1 when it applied
+int nco_code_period(double ti, double codefreq, int len, double remcode, int smax, int nt, double *rem)
+{
+    GcCodePlan P;
+    gc_code_plan_init(P, ti * codefreq, len, smax);
+    GcFillLoop fill;
+    return gc_code_period(P, remcode, nt, fill, rem) ? 1 : 0;
+}
+
+int nco_carrier_period(double ti, double freq, double remcarr, int n, double *prem)
+{
+    GcCarPlan P;
+    gc_car_plan_init(P, gc_carrier_ps(freq, ti));
+    GcFillLoop fill;
+    return gc_carrier_period(P, remcarr, n, fill, prem) ? 1 : 0;
+}
+
 // end values only (what the planner chains)
 void nco_chain(double phi0, double freq, double ti, int n, int len, double coff, int smax, double ci,
                double *prem, double *rem)

@@ -26,6 +26,12 @@ def nco(tmp_path_factory):
     L.nco_carrier.argtypes = [d, d, d, i, i, vp, C.POINTER(d)]
     L.nco_code.argtypes = [i, d, i, d, i, i, vp, C.POINTER(d)]
     L.nco_chain.argtypes = [d, d, d, i, i, d, i, d, C.POINTER(d), C.POINTER(d)]
+    L.nco_chain_fast.argtypes = [d, d, d, d, d, i, d, i, C.POINTER(i), C.POINTER(d), C.POINTER(d)]
+    L.nco_chain_cert.argtypes = [d, d, d, d, d, i, d, i, C.POINTER(i), C.POINTER(d), C.POINTER(d), C.POINTER(i)]
+    L.nco_code_period.argtypes = [d, d, i, d, i, i, C.POINTER(d)]
+    L.nco_carrier_period.argtypes = [d, d, d, i, C.POINTER(d)]
+    L.nco_carrier_fast.argtypes = L.nco_carrier.argtypes
+    L.nco_code_fast.argtypes = L.nco_code.argtypes
     return L
 
 
@@ -48,7 +54,13 @@ def _carrier_case(nco, orc, phi0, freq, ti, n, cap=48):
     bad = np.flatnonzero((cost[idx] != I) | (sint[idx] != Q))
     assert bad.size == 0, f"phi0={phi0!r} freq={freq!r} n={n}: {bad.size} samples differ, first {bad[:5]}"
     assert prem.value == oprem, f"phi0={phi0!r} freq={freq!r}: prem {prem.value!r} != {oprem!r}"
-    return nseg
+    # the tabulated fast walker: same indices, same remainder
+    idx2 = np.zeros(n, np.int32)
+    prem2 = C.c_double()
+    nseg2 = nco.nco_carrier_fast(phi0, freq, ti, n, cap + 8, idx2.ctypes.data, C.byref(prem2))
+    assert nseg2 > 0 and np.array_equal(idx & 31, idx2 & 31) and prem2.value == oprem, \
+        f"fast walker: phi0={phi0!r} freq={freq!r} n={n}"
+    return max(nseg, nseg2)
 
 
 def _code_case(nco, orc, length, coff, smax, ci, n, cap=32):
@@ -68,7 +80,11 @@ def _code_case(nco, orc, length, coff, smax, ci, n, cap=32):
     bad = np.flatnonzero(chip != rc)
     assert bad.size == 0, f"len={length} coff={coff!r} ci={ci!r} n={n}: {bad.size} chips differ, first {bad[:5]}"
     assert rem.value == orem, f"coff={coff!r} ci={ci!r}: rem {rem.value!r} != {orem!r}"
-    return nseg
+    chip2 = np.zeros(nt, np.int32)
+    rem2 = C.c_double()
+    nseg2 = nco.nco_code_fast(length, coff, smax, ci, n, cap + 8, chip2.ctypes.data, C.byref(rem2))
+    assert nseg2 > 0 and np.array_equal(chip2, rc) and rem2.value == orem, f"fast walker: coff={coff!r} ci={ci!r} n={n}"
+    return max(nseg, nseg2)
 
 
 def test_carrier_grid_frequencies_from_zero_phase(nco, orc):
@@ -184,6 +200,7 @@ def test_chain_matches_literal_loops_over_many_periods(nco, orc):
         codefreq = 1.023e6 + [0.0, 1.4, -2.7, 0.3, 2.9, -0.01][case]
         remcode, remcarr = 0.0, 0.0
         code = np.arange(1023, dtype=np.int16)
+        ncert = {}
         for _ in range(300):
             n = int((1023 - remcode) / (codefreq / F_SF))
             data = np.ones(n, np.int8)
@@ -194,4 +211,112 @@ def test_chain_matches_literal_loops_over_many_periods(nco, orc):
             prem, rem = C.c_double(), C.c_double()
             nco.nco_chain(remcarr, carrfreq, ti, n, 1023, remcode, 6, ti * codefreq, C.byref(prem), C.byref(rem))
             assert prem.value == oprem and rem.value == orem
+            # the device planner's own formulation of the step (reciprocal divisions, tabulated walkers)
+            n2, prem2, rem2 = C.c_int(), C.c_double(), C.c_double()
+            nco.nco_chain_fast(remcarr, carrfreq, ti, F_SF, codefreq, 1023, remcode, 6, C.byref(n2), C.byref(prem2),
+                               C.byref(rem2))
+            assert n2.value == n and prem2.value == oprem and rem2.value == orem
+            # ... and through certified crossings
+            used = C.c_int()
+            nco.nco_chain_cert(remcarr, carrfreq, ti, F_SF, codefreq, 1023, remcode, 6, C.byref(n2), C.byref(prem2),
+                               C.byref(rem2), C.byref(used))
+            assert n2.value == n and prem2.value == oprem and rem2.value == orem
+            ncert[used.value] = ncert.get(used.value, 0) + 1
             remcode, remcarr = orem, oprem
+        # the certified path must be the one that normally runs (both NCOs: used == 3).  Exceptions, all
+        # served by the piece walkers: the MHz carriers (phase runs off the 20-binade table), and a carrier
+        # exactly on the 200 Hz acquisition grid, whose exact-arithmetic phase hits binade boundaries to
+        # the last bit (2200 Hz * 32 / 16.368 MHz * 465 = 2) so that no crossing can be certified there
+        if carrfreq in (137.77, 5000.0, -1400.0):
+            assert ncert.get(3, 0) >= 295, ncert
+        # (the first period starts from code phase exactly 0: its sixth sample lands on the code length to
+        # the last bit -- not certifiable either)
+        assert ncert.get(3, 0) + ncert.get(2, 0) >= 299, ncert
+
+
+def test_certified_chain_random_states(nco, orc):
+    """Certified crossings against the literal loops on random (also unlocked) states: whatever path the
+    planner takes, the three chained values are the reference's."""
+    rng = np.random.default_rng(77)
+    ti = 1 / F_SF
+    L = orc.lib()
+    code = np.arange(1023, dtype=np.int16)
+    used_hist = {}
+    for it in range(3000):
+        carrfreq = float(rng.choice([0.0, 4.092e6]) + rng.uniform(-9000, 9000))
+        codefreq = 1.023e6 + float(rng.uniform(-8, 8)) * (it % 7 != 0)
+        remcode = float([0.0, rng.uniform(0, 0.2), rng.uniform(0, 1023), rng.integers(0, 1023)][it % 4])
+        remcarr = float([0.0, rng.uniform(0, DPI), -rng.uniform(0, 1e4), rng.uniform(0, 1e-6)][(it // 4) % 4])
+        smax = int(rng.choice([3, 6, 18]))
+        n = int((1023 - remcode) / (codefreq / F_SF))
+        if n < 1:
+            continue
+        data = np.ones(n, np.int8)
+        I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        rc = np.zeros(n + 2 * smax, np.int16)
+        oprem = L.orc_mixcarr_seq(data.ctypes.data, 1, ti, n, carrfreq, remcarr, I.ctypes.data, Q.ctypes.data)
+        orem = L.orc_rescode_seq(code.ctypes.data, 1023, remcode, smax, ti * codefreq, n, rc.ctypes.data)
+        n2, prem2, rem2, used = C.c_int(), C.c_double(), C.c_double(), C.c_int()
+        nco.nco_chain_cert(remcarr, carrfreq, ti, F_SF, codefreq, 1023, remcode, smax, C.byref(n2), C.byref(prem2),
+                           C.byref(rem2), C.byref(used))
+        assert n2.value == n and prem2.value == oprem and rem2.value == orem, (it, carrfreq, codefreq, remcode, remcarr)
+        used_hist[used.value] = used_hist.get(used.value, 0) + 1
+    assert used_hist.get(3, 0) + used_hist.get(2, 0) > 2000, used_hist
+
+
+def test_code_period_step(nco, orc):
+    """The planner's shape-specialised code step: whenever it applies, its remainder is the literal loop's;
+    and for a tracked channel (small remcode, any chip rate near nominal, any tap span) it applies."""
+    rng = np.random.default_rng(123)
+    ti = 1 / F_SF
+    L = orc.lib()
+    applied = 0
+    total = 0
+    for it in range(4000):
+        length, crate = (1023, 1.023e6) if it % 4 else (511, 0.511e6)
+        codefreq = crate + float(rng.uniform(-8, 8)) * (it % 9 != 0)
+        ci = ti * codefreq
+        remcode = float([rng.uniform(0, ci), 0.0, rng.uniform(-ci, 2 * ci), rng.uniform(0, length)][it % 4 if it % 16 else 3])
+        smax = int(rng.choice([3, 6, 9, 18, 40]))
+        n = int((length - remcode) / (codefreq / F_SF))
+        if n < 100:
+            continue
+        code = np.arange(length, dtype=np.int16)
+        rc = np.zeros(n + 2 * smax, np.int16)
+        orem = L.orc_rescode_seq(code.ctypes.data, length, remcode, smax, ci, n, rc.ctypes.data)
+        rem = C.c_double()
+        ok = nco.nco_code_period(ti, codefreq, length, remcode, smax, n + 2 * smax, C.byref(rem))
+        tracked = 0.0 < remcode < ci
+        total += tracked
+        if ok:
+            assert rem.value == orem, (it, codefreq, remcode, smax, rem.value, orem)
+            applied += tracked
+    assert total > 800 and applied >= 0.99 * total, (applied, total)
+
+
+def test_carrier_period_step(nco, orc):
+    """The planner's carrier step: its remainder is the literal loop's whenever it applies, and it applies to
+    the states a tracked channel has (zero IF and the 4 MHz IF of frontend/iffile.ini, either Doppler sign,
+    phases wrapped to [0, 2 pi] or -- negative -- grown for seconds)."""
+    rng = np.random.default_rng(321)
+    ti = 1 / F_SF
+    L = orc.lib()
+    applied = total = 0
+    for it in range(4000):
+        f_if = [0.0, 4.092e6, 0.0, -3.94e6][it % 4]
+        freq = f_if + float(rng.uniform(-9000, 9000))
+        if freq > 0:
+            remcarr = float([rng.uniform(0, DPI), 0.0, rng.uniform(0, 1e-3)][it % 3])
+        else:
+            remcarr = -float(rng.uniform(0, 1)) * 10.0 ** float(rng.uniform(-2, 5.5))
+        n = int(rng.integers(16300, 16400))
+        data = np.ones(n, np.int8)
+        I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        oprem = L.orc_mixcarr_seq(data.ctypes.data, 1, ti, n, freq, remcarr, I.ctypes.data, Q.ctypes.data)
+        prem = C.c_double()
+        ok = nco.nco_carrier_period(ti, freq, remcarr, n, C.byref(prem))
+        total += 1
+        if ok:
+            assert prem.value == oprem, (it, freq, remcarr, prem.value, oprem)
+            applied += 1
+    assert applied >= 0.9 * total, (applied, total)
