@@ -826,11 +826,13 @@ __device__ __forceinline__ bool cert_stretch_dev(const GcNcoFast &f, double *px,
     if (lane > i0 && lane <= GC_NB && (lane <= ilim || lane == GC_NB)) Kl = gc_cert_lane(c, lane, lim);
     if (__any(Kl == GC_CERT_FAIL)) return false;
     if (lane <= GC_NB) Ks[lane] = Kl;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         // (one wavefront: LDS order suffices)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double y = *px;
     int k = 0;
     const bool ok = gc_cert_chain(f, &y, &k, c.n, i0, Ks, ilim, Ks[GC_NB]);
-    __syncthreads();                                                               // before Ks is rewritten
+    __builtin_amdgcn_wave_barrier();                                               // before Ks is rewritten
     if (!ok) return false;
     *px = y;
     *pk += k;

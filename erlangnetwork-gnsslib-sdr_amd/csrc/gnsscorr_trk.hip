@@ -34,17 +34,28 @@ namespace {
 // running sums cross it (certified against the accumulated rounding, gnsscorr_nco.h); what is left
 // to the sequential chain is one fma and one addition per binade.
 
-__global__ __launch_bounds__(64) void trk_plan_kernel(const GcChan *__restrict__ chan,
-                                                      const GcTrkState *__restrict__ state_in,
-                                                      GcTrkState *__restrict__ state_out,
-                                                      GcTrkPlan *__restrict__ plan, int nch, int nepoch)
+// Two wavefronts per channel: wavefront 0 chains the code NCO (and with it the samples per period and the
+// buffer positions), wavefront 1 follows one step behind with the carrier NCO, which needs only the
+// period lengths -- the two chains are independent otherwise and each is latency bound.
+#define GC_PLAN_MAXE 4096          // periods per batch handed from wave to wave through LDS (longer: one wave does both)
+__global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict__ chan,
+                                                       const GcTrkState *__restrict__ state_in,
+                                                       GcTrkState *__restrict__ state_out,
+                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch)
 {
-    __shared__ int Ks[GC_NB + 2];
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    __shared__ int Ks2[2][GC_NB + 2];
+    __shared__ int nsh[GC_PLAN_MAXE];
+    __shared__ int prog;
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (ch >= nch) return;
     // the chain is latency bound and shares its SIMD with correlator wavefronts of the batch before:
     // let it issue first
     __builtin_amdgcn_s_setprio(3);
+    const bool split = nepoch <= GC_PLAN_MAXE;          // else wavefront 0 does both chains
+    if (threadIdx.x == 0) prog = 0;
+    __syncthreads();
+    if (!split && wave == 1) return;
+    int *Ks = Ks2[wave];
     const GcChan c = chan[ch];
     GcTrkState s = state_in[ch];
     const double ci = __dmul_rn(c.ti, s.codefreq);          // ti*crate, ref src/sdrcmn.c:709
@@ -52,58 +63,79 @@ __global__ __launch_bounds__(64) void trk_plan_kernel(const GcChan *__restrict__
     const double ps = gc_carrier_ps(s.carrfreq, c.ti);
     const double dlen = (double)c.clen;
     const bool code_ok = ci > 0.0 && ci < dlen;             // the reference's one-subtraction wrap (:617) needs it
-    GcTrkPlan p;
-    p.carrfreq = s.carrfreq;
-    p.codefreq = s.codefreq;
-    p.pad = 0;
     GcTrkPlan *out = plan + (size_t)ch * nepoch;
     GcNoEmit ne;
-    // per-binade constants of the addends: the frequencies are held over the batch
+    GcFillLanes fill{lane};
+    const bool do_code = wave == 0, do_car = wave == 1 || !split;
+    // per-binade constants of the addends (the frequencies are held over the batch) and the
+    // shape-specialised period steps built on them
     GcNcoFast fcar, fcode, fprem;
-    gc_fast_init(fcar, ps);
-    gc_fast_init(fcode, ci);
-    gc_fast_init(fprem, -GC_NCO_DPI);
-    // ... and the shape-specialised period steps built on them
     GcCodePlan PC;
     GcCarPlan PK;
-    gc_code_plan_init(PC, ci, c.clen, c.smax);
-    gc_car_plan_init(PK, ps);
-    GcFillLanes fill{lane};
+    if (do_code) { gc_fast_init(fcode, ci); gc_code_plan_init(PC, ci, c.clen, c.smax); }
+    if (do_car) { gc_fast_init(fcar, ps); gc_fast_init(fprem, -GC_NCO_DPI); gc_car_plan_init(PK, ps); }
     const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
     const double smaxci = __dmul_rn((double)c.smax, ci);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
     for (int e = 0; e < nepoch; e++) {
-        const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
-        const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
-        const int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
-        p.buffloc = s.buffloc;
-        p.coff = s.remcode;
-        p.phi0 = s.remcarr;
-        p.n = n;
-        if (lane == 0) out[e] = p;
-        if (n > 0 && n <= (1 << 24)) {
-            double rp, rc;
-            if (gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
+        int n;
+        if (do_code) {
+            const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
+            const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
+            n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
+            if (lane == 0) {
+                out[e].buffloc = s.buffloc;
+                out[e].coff = s.remcode;
+                out[e].carrfreq = s.carrfreq;
+                out[e].codefreq = s.codefreq;
+                out[e].n = n;
+                out[e].pad = 0;
+            }
+            if (split) {
+                if (lane == 0) nsh[e] = n;
+                __threadfence_block();
+                if (lane == 0) __hip_atomic_store(&prog, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            while (__hip_atomic_load(&prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= e) __builtin_amdgcn_s_sleep(1);
+            n = nsh[e];
+        }
+        const bool walk = n > 0 && n <= (1 << 24);
+        if (do_car) {
+            if (lane == 0) out[e].phi0 = s.remcarr;
+            double rp;
+            if (walk && gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
                 s.remcarr = rp;
-            } else {                // any other shape: the general walkers
+            } else if (walk) {      // any other shape: the general walkers
                 const double phis = gc_div_y(__dmul_rn(s.remcarr, GC_NCO_CDIV), GC_NCO_DPI, ydpi);     // ref src/sdrcmn.c:649
                 double xn;
                 if (!plan_carrier_dev(fcar, phis, n, Ks, lane, &xn)) xn = gc_fast_carrier_walk(fcar, phis, n, ne);
                 s.remcarr = gc_fast_prem(fprem, xn);
             }
-            if (code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
+        }
+        if (do_code) {
+            double rc;
+            if (walk && code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
                 s.remcode = rc;
-            } else if (code_ok) {
+            } else if (walk && code_ok) {
                 const double c0 = gc_code_start_fast(s.remcode, smaxci, c.clen);
                 double cend;
                 if (!plan_code_dev(fcode, c0, c.clen, n + 2 * c.smax, Ks, lane, &cend))
                     cend = gc_fast_code_walk(fcode, c0, c.clen, n + 2 * c.smax, ne);
                 s.remcode = __dsub_rn(cend, smaxci);
             }
+            s.buffloc += (uint64_t)(int64_t)n;
         }
-        s.buffloc += (uint64_t)(int64_t)n;
     }
-    if (lane == 0) state_out[ch] = s;
+    if (lane == 0) {
+        if (do_code) {
+            state_out[ch].carrfreq = s.carrfreq;
+            state_out[ch].codefreq = s.codefreq;
+            state_out[ch].remcode = s.remcode;
+            state_out[ch].buffloc = s.buffloc;
+        }
+        if (do_car) state_out[ch].remcarr = s.remcarr;
+    }
 }
 
 // rounds per workgroup of the prefix-sum correlator: a whole period when it fits GC_MAXR rounds
@@ -1102,7 +1134,7 @@ int gc_trk_nseg(int dtype, int max_n)
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch)
 {
-    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(64), 0, st, chan, state_in, state_out, plan,
+    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan,
                        nch, nepoch);
     GC_HIP(hipGetLastError());
     return 0;
