@@ -48,6 +48,26 @@ class TrkState(C.Structure):
                 ("remcarr", C.c_double), ("buffloc", C.c_uint64)]
 
 
+MAXTAPS = 33
+
+
+class LoopState(C.Structure):
+    """gnsscorr_loop_t (include/gnsscorr.h): loop-filter configuration and state of one channel."""
+    _fields_ = ([(n, C.c_double) for n in ("acqfreq", "f_if", "foffset", "f_cf", "crate", "ctime")] +
+                [(n, C.c_double * 2) for n in ("pllaw", "pllw2", "fllw", "dllaw", "dllw2")] +
+                [(n, C.c_int) for n in ("ne", "nl", "loopms", "rate", "flagsync", "synci", "navcnt", "swloop")] +
+                [("cnt", C.c_uint64)] +
+                [(n, C.c_double) for n in ("carrNco", "codeNco", "carrErr", "codeErr", "freqErr")] +
+                [(n, C.c_double * MAXTAPS) for n in ("II", "QQ", "oldI", "oldQ", "sumI", "sumQ", "oldsumI", "oldsumQ")])
+
+
+class TrkLog(C.Structure):
+    """gnsscorr_trklog_t: one row per code period of a closed-loop run."""
+    _fields_ = ([(n, C.c_double) for n in ("carrfreq", "codefreq", "carrErr", "codeErr", "carrNco", "codeNco", "freqErr",
+                                            "remcode", "remcarr")] +
+                [("buffloc", C.c_uint64), ("currnsamp", C.c_int), ("flagloopfilter", C.c_int)])
+
+
 class AcqRes(C.Structure):
     _fields_ = [("acqcodei", C.c_int), ("freqi", C.c_int), ("acqfreq", C.c_double),
                 ("cn0", C.c_double), ("peakr", C.c_double), ("flagacq", C.c_int),
@@ -169,6 +189,10 @@ def lib():
     L.gnsscorr_trk_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gnsscorr_trk_fetch_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gnsscorr_trk_devptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.gnsscorr_loop_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(LoopState)]
+    L.gnsscorr_loop_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(LoopState)]
+    L.gnsscorr_trk_run_loop.argtypes = [C.c_void_p, C.c_int]
+    L.gnsscorr_trk_fetch_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gnsscorr_acq_run.argtypes = [C.c_void_p, C.c_uint64]
     L.gnsscorr_acq_fetch.argtypes = [C.c_void_p, C.POINTER(AcqRes)]
     L.gnsscorr_trk_start_from_acq.argtypes = [C.c_void_p]
@@ -379,6 +403,48 @@ class Engine:
         sQ = np.empty((nch, nt), np.float64)
         _check(self._L.gnsscorr_trk_fetch_sums(self.h, sI.ctypes.data, sQ.ctypes.data))
         return sI, sQ
+
+    # -- closed loop
+    def loop_state(self, ch, acqfreq, dllb=(5.0, 1.0), pllb=(30.0, 10.0), fllb=(200.0, 50.0), flagsync=0, synci=0,
+                   cnt=0, loop=None):
+        """A LoopState for channel index `ch` with the constants inittrkprmstruct()/inittrkstruct() derive
+        (ref src/sdrinit.c:402-425,432-480) and zeroed filter state."""
+        c = self.channels[ch]
+        ls = LoopState()
+        ls.acqfreq, ls.f_if, ls.foffset, ls.f_cf, ls.crate, ls.ctime = acqfreq, c.f_if, c.foffset, c.f_cf, c.crate, c.ctime
+        for i in range(2):
+            ls.dllw2[i] = (dllb[i] / 0.53) * (dllb[i] / 0.53)
+            ls.dllaw[i] = 1.414 * (dllb[i] / 0.53)
+            ls.pllw2[i] = (pllb[i] / 0.53) * (pllb[i] / 0.53)
+            ls.pllaw[i] = 1.414 * (pllb[i] / 0.53)
+            ls.fllw[i] = fllb[i] / 0.25
+        ls.ne, ls.nl = c.ne, c.nl
+        loop = loop if loop is not None else (2 if c.ctype == CTYPE_L1SBAS else 10)
+        ls.loopms = loop * int(c.ctime * 1000)
+        ls.rate = 10 if c.ctype == CTYPE_G1 else (2 if c.ctype == CTYPE_L1SBAS else 20)
+        ls.flagsync, ls.synci, ls.cnt = flagsync, synci, cnt
+        return ls
+
+    def loop_set(self, states, ch0=0):
+        arr = (LoopState * len(states))(*states)
+        _check(self._L.gnsscorr_loop_set(self.h, ch0, len(states), arr))
+
+    def loop_get(self, ch0=0, nch=None):
+        nch = len(self.channels) - ch0 if nch is None else nch
+        arr = (LoopState * nch)()
+        _check(self._L.gnsscorr_loop_get(self.h, ch0, nch, arr))
+        return list(arr)
+
+    def trk_run_loop(self, nperiod):
+        _check(self._L.gnsscorr_trk_run_loop(self.h, nperiod))
+        self._nepoch = nperiod
+
+    def trk_fetch_log(self):
+        nch = len(self.channels)
+        log = np.zeros((nch, self._nepoch), dtype=np.dtype(TrkLog))
+        ndone = np.zeros(nch, np.int32)
+        _check(self._L.gnsscorr_trk_fetch_log(self.h, log.ctypes.data, ndone.ctypes.data))
+        return log, ndone
 
     # -- acquisition
     def acq_run(self, wrpos=0):

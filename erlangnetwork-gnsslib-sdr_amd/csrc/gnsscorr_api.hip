@@ -71,6 +71,11 @@ static void free_channels(gnsscorr_ctx *ctx)
     hipFree(ctx->dcodes); ctx->dcodes = nullptr;
     hipFree(ctx->dfreqs); ctx->dfreqs = nullptr;
     for (int i = 0; i < 2; i++) { hipFree(ctx->dstate2[i]); ctx->dstate2[i] = nullptr; }
+    hipFree(ctx->dloop); ctx->dloop = nullptr;
+    hipFree(ctx->dloopdone); ctx->dloopdone = nullptr;
+    hipFree(ctx->dlooplog); ctx->dlooplog = nullptr;
+    ctx->looplog_cap = 0;
+    ctx->last_loop_nper = 0;
     ctx->state_cur = 0;
     ctx->ahead_valid = false;
     ctx->state_touched = true;
@@ -331,6 +336,10 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
         GC_HIP(hipMalloc((void **)&ctx->dstate2[i], sizeof(GcTrkState) * nch));
         GC_HIP(hipMemsetAsync(ctx->dstate2[i], 0, sizeof(GcTrkState) * nch, ctx->stream));
     }
+    GC_HIP(hipMalloc((void **)&ctx->dloop, sizeof(gnsscorr_loop_t) * nch));
+    GC_HIP(hipMemsetAsync(ctx->dloop, 0, sizeof(gnsscorr_loop_t) * nch, ctx->stream));
+    GC_HIP(hipMalloc((void **)&ctx->dloopdone, sizeof(int) * nch + sizeof(uint64_t) * nch + 8));
+    GC_HIP(hipMemsetAsync(ctx->dloopdone, 0, sizeof(int) * nch + sizeof(uint64_t) * nch + 8, ctx->stream));
     GC_HIP(hipMemcpyAsync(ctx->dcodes, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipMemcpyAsync(ctx->dfreqs, freqs.data(), sizeof(double) * freqs.size(), hipMemcpyHostToDevice,
                           ctx->stream));
@@ -344,6 +353,8 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
 }
 
 extern "C" int gnsscorr_num_channels(gnsscorr_ctx *ctx) { return ctx ? ctx->nch : 0; }
+
+static int nco_check(gnsscorr_ctx *ctx);
 
 // ---------------------------------------------------------------------------
 // tracking
@@ -500,7 +511,107 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     }
     ctx->last_slot = slot;
     ctx->last_nepoch = nepoch;
+    ctx->last_loop_nper = 0;
     return GNSSCORR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tracking, closed loop
+// ---------------------------------------------------------------------------
+static int loop_quiesce(gnsscorr_ctx *ctx)
+{
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ahead_valid = false;                                         // ... and is dropped
+    ctx->state_touched = true;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_loop_set(gnsscorr_ctx *ctx, int ch0, int nch, const gnsscorr_loop_t *lp)
+{
+    if (!ctx || !lp || ch0 < 0 || nch <= 0 || ch0 + nch > ctx->nch)
+        return gc_fail(GNSSCORR_EINVAL, "loop_set: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
+    for (int i = 0; i < nch; i++) {
+        const gnsscorr_loop_t &l = lp[i];
+        const int ntap = ctx->hchan[ch0 + i].ntap;
+        if (l.ne < 0 || l.ne >= ntap || l.nl < 0 || l.nl >= ntap)
+            return gc_fail(GNSSCORR_EINVAL, "loop_set: channel %d: early/late tap index %d/%d of %d taps", ch0 + i, l.ne, l.nl, ntap);
+        if (l.loopms < 1 || l.rate < 1)
+            return gc_fail(GNSSCORR_EINVAL, "loop_set: channel %d: loopms %d, rate %d", ch0 + i, l.loopms, l.rate);
+    }
+    GC_HIP(hipSetDevice(ctx->device));
+    { int rc = loop_quiesce(ctx); if (rc) return rc; }
+    GC_HIP(hipMemcpyAsync(ctx->dloop + ch0, lp, sizeof(gnsscorr_loop_t) * nch, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_loop_get(gnsscorr_ctx *ctx, int ch0, int nch, gnsscorr_loop_t *lp)
+{
+    if (!ctx || !lp || ch0 < 0 || nch <= 0 || ch0 + nch > ctx->nch)
+        return gc_fail(GNSSCORR_EINVAL, "loop_get: channel range [%d,%d) of %d", ch0, ch0 + nch, ctx ? ctx->nch : 0);
+    GC_HIP(hipSetDevice(ctx->device));
+    { int rc = loop_quiesce(ctx); if (rc) return rc; }
+    GC_HIP(hipMemcpyAsync(lp, ctx->dloop + ch0, sizeof(gnsscorr_loop_t) * nch, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
+{
+    if (!ctx || nperiod <= 0) return gc_fail(GNSSCORR_EINVAL, "trk_run_loop: nperiod %d", nperiod);
+    if (!ctx->nch) return gc_fail(GNSSCORR_ESTATE, "trk_run_loop: no channels set");
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_trk_buffers(ctx, nperiod);
+    if (rc) return rc;
+    // the look-ahead planner of the batched interface works on the same state: stop it, drop its plan
+    if (ctx->ahead_valid || ctx->fin_pending[0] || ctx->fin_pending[1]) { rc = loop_quiesce(ctx); if (rc) return rc; }
+    ctx->ahead_valid = false;
+    ctx->state_touched = true;
+    const size_t units = (size_t)ctx->nch * nperiod;
+    if (units > ctx->looplog_cap) {
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->dlooplog); ctx->dlooplog = nullptr; ctx->looplog_cap = 0;
+        GC_HIP(hipMalloc((void **)&ctx->dlooplog, sizeof(gnsscorr_trklog_t) * units));
+        ctx->looplog_cap = units;
+    }
+    GC_HIP(hipMemsetAsync(ctx->dlooplog, 0, sizeof(gnsscorr_trklog_t) * units, ctx->stream));
+    GC_HIP(hipMemsetAsync(ctx->dcorrI, 0, sizeof(double) * units * ctx->ntap, ctx->stream));
+    GC_HIP(hipMemsetAsync(ctx->dcorrQ, 0, sizeof(double) * units * ctx->ntap, ctx->stream));
+    GC_HIP(hipMemsetAsync(ctx->dnsamp2[0], 0, sizeof(int) * units, ctx->stream));
+    // write position of each channel's ring (ref src/sdrtrk.c:26-28: fendbuffsize*buffcnt)
+    std::vector<uint64_t> wp(ctx->nch);
+    for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
+    uint64_t *dwp = reinterpret_cast<uint64_t *>(ctx->dloopdone + ctx->nch + (ctx->nch & 1));
+    GC_HIP(hipMemcpyAsync(dwp, wp.data(), sizeof(uint64_t) * ctx->nch, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));          // (wp is a local)
+    bool have[3] = {false, false, false};
+    for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
+    for (int dtype = 1; dtype <= 2; dtype++) {
+        if (!have[dtype]) continue;
+        GcTimed t(ctx, "trk_loop");
+        rc = gc_launch_trk_loop(ctx->stream, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dloop, dwp, ctx->dcorrI, ctx->dcorrQ,
+                                ctx->dnsamp2[0], ctx->dlooplog, ctx->dloopdone, ctx->dnco_overflow, ctx->nch, nperiod, ctx->nseg,
+                                dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+        if (rc) return rc;
+    }
+    ctx->last_slot = 0;
+    ctx->fin_pending[0] = ctx->fin_pending[1] = false;
+    ctx->last_nepoch = nperiod;
+    ctx->last_loop_nper = nperiod;
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_trk_fetch_log(gnsscorr_ctx *ctx, gnsscorr_trklog_t *log, int *ndone)
+{
+    if (!ctx || !ctx->last_loop_nper) return gc_fail(GNSSCORR_ESTATE, "trk_fetch_log: no completed trk_run_loop");
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t units = (size_t)ctx->nch * ctx->last_loop_nper;
+    if (log) GC_HIP(hipMemcpyAsync(log, ctx->dlooplog, sizeof(gnsscorr_trklog_t) * units, hipMemcpyDeviceToHost, ctx->stream));
+    if (ndone) GC_HIP(hipMemcpyAsync(ndone, ctx->dloopdone, sizeof(int) * ctx->nch, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return nco_check(ctx);
 }
 
 // Units whose NCO piece tables overflowed (a code step that wraps the code more than ~twice per call, a
@@ -536,6 +647,7 @@ extern "C" int gnsscorr_trk_fetch(gnsscorr_ctx *ctx, double *trkII, double *trkQ
 extern "C" int gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ)
 {
     if (!ctx || !ctx->last_nepoch) return gc_fail(GNSSCORR_ESTATE, "trk_fetch_sums: no completed trk_run");
+    if (ctx->last_loop_nper) return gc_fail(GNSSCORR_ESTATE, "trk_fetch_sums: the last run was closed loop (its sums are in gnsscorr_loop_get)");
     GC_HIP(hipSetDevice(ctx->device));
     { int rc = outputs_ready(ctx); if (rc) return rc; }
     const size_t n = (size_t)ctx->nch * ctx->ntap;

@@ -64,7 +64,15 @@ struct gnsscorr_ctx {
     GcTrkUnit *dunit2[2] = {nullptr, nullptr};
     GcRound *drounds2[2] = {nullptr, nullptr};     // [unit][nseg][GC_MAXR]
     GcUnitSegs *dsegs2[2] = {nullptr, nullptr};    // [unit]: the unit's carrier / code NCO piece tables
-    int *dnco_overflow = nullptr;                  // units whose NCO tables overflowed since the last fetch
+    int *dnco_overflow = nullptr;
+    // closed loop (gnsscorr_trk_run_loop): per channel loop state, NCO tables of the period at hand,
+    // one log row per period
+    gnsscorr_loop_t *dloop = nullptr;              // [nch]
+    GcUnitSegs *dloopsegs = nullptr;               // [nch]
+    gnsscorr_trklog_t *dlooplog = nullptr;         // [nch][looplog_cap]
+    int *dloopdone = nullptr;                      // [nch]
+    size_t looplog_cap = 0;
+    int last_loop_nper = 0;                        // > 0: the last run was a closed-loop one of that many periods                  // units whose NCO tables overflowed since the last fetch
     int *dnsamp2[2] = {nullptr, nullptr};
     int last_slot = 0;                             // slot of the last completed trk_run
     size_t plan_cap = 0;

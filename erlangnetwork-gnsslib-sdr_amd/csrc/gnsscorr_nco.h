@@ -358,7 +358,8 @@ struct GcNcoFast {
     double inv[GC_NB];          // 1/|d| (0 when d = 0)
 };
 
-GC_HD void gc_fast_init(GcNcoFast &f, double s)
+// with_inv = false leaves inv[] zero (the period steps need only inv_s and, for the code, inv[itop])
+GC_HD void gc_fast_init(GcNcoFast &f, double s, bool with_inv = true)
 {
     GC_FP_STRICT
     const uint64_t us = gc_d2u(s);
@@ -383,7 +384,7 @@ GC_HD void gc_fast_init(GcNcoFast &f, double s)
             if (fabs(t - b) == 0.5) f.tie |= 1u << i;
         }
         f.d[i] = ldexp(b, ex - 1075);
-        if (b != 0.0) f.inv[i] = 1.0 / fabs(f.d[i]);
+        if (b != 0.0 && with_inv) f.inv[i] = 1.0 / fabs(f.d[i]);
     }
 }
 
@@ -772,7 +773,7 @@ GC_HD bool gc_plan_code_walk(const GcNcoFast &f, double c, int len, int nt, int 
 // A sum far above its addend (a negative carrier phase is never wrapped, ref src/sdrcmn.c:667: after a
 // fraction of a second it is thousands of LUT steps while the step stays ~0.01) spends the whole period
 // inside one binade: n equal steps d = RN_u(s), if the last one stays below the top of the binade.
-GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn)
+GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn, double *dout = nullptr)
 {
     GC_FP_STRICT
     const uint64_t ux = gc_d2u(x), us = gc_d2u(s);
@@ -791,6 +792,7 @@ GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn)
     const double top = fabs(gc_u2d(ux | 0x000FFFFFFFFFFFFFull));
     if (!(fabs(y) <= top)) return false;
     *xn = y;
+    if (dout) *dout = d;
     return true;
 }
 
@@ -900,10 +902,10 @@ struct GcCodePlan {
     bool   ok;              // the table covers the code (else: general walkers only)
 };
 
-GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax)
+GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax, bool with_inv = true)
 {
     GC_FP_STRICT
-    gc_fast_init(P.f, ci);
+    gc_fast_init(P.f, ci, with_inv);
     P.dlen = (double)len;
     P.smaxci = (double)smax * ci;
     P.limtop = gc_u2d(gc_d2u(P.dlen) - 1);
@@ -911,6 +913,11 @@ GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax)
     P.ok = P.f.ex0 != 0x7FFFFFF && ci > 0.0 && P.itop >= 1 && P.itop < GC_NB &&
            P.dlen + ci < gc_u2d((uint64_t)(P.f.ex0 + P.itop + 1) << 52) && !((P.f.tie >> P.itop) & 1);
     P.exact = P.ok && gc_cert_exact(P.limtop, ci, P.dlen);
+    if (P.ok && !with_inv) {
+#pragma unroll
+        for (int i = 0; i < GC_NB; i++)
+            if (i == P.itop && P.f.d[i] != 0.0) P.f.inv[i] = 1.0 / fabs(P.f.d[i]);
+    }
 }
 
 // fill(K, ctx, i0, itop, lim): K[i] = certified crossing of boundary i (i0 < i <= itop: bottom of table
@@ -927,8 +934,10 @@ struct GcFillLoop {
     }
 };
 
-template <class Fill>
-GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out)
+// emit(j0, y0, d, count, w) receives the pieces (as gc_code_walk's emitter does) when the step applies;
+// on a false return the emitter may have seen some pieces already: reset it before the fallback.
+template <class Fill, class Emit>
+GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
 {
     GC_FP_STRICT
     if (!P.ok) return false;
@@ -951,12 +960,14 @@ GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fil
         if (!(q >= 0.0 && q < (double)(nt - 2))) return false;
         y = fma(q + 1.0, dtop, c0) - dlen;          // first sample at or above len, wrapped (exact)
         j = (int)q + 1;
+        emit(0, c0, dtop, j, 0);
     }
     // ---- next to zero: the reference's own additions up to the table
     const double b0 = gc_u2d((uint64_t)f.ex0 << 52);
 #pragma unroll
     for (int t = 0; t < 5; t++) {
         const bool lit = y < b0;
+        if (lit) emit(j, y, 0.0, 1, 1);
         const double yl = y + ci;
         y = lit ? yl : y;
         j += lit ? 1 : 0;
@@ -984,12 +995,16 @@ GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fil
         last = last > c.n - 1 ? c.n - 1 : last;
         int m = last - k;
         ok = ok && m >= 0;
+        int kb = k;
         if ((f.tie >> i) & 1) {                     // (at most one table binade: a uniform branch)
             const bool odd = (gc_d2u(y) & 1) && m > 0;
+            if (odd) emit(j + kb, y, 0.0, 1, 1);
             const double yl = y + ci;
             y = odd ? yl : y;
             m -= odd ? 1 : 0;
+            kb += odd ? 1 : 0;
         }
+        if (m >= 0) emit(j + kb, y, f.d[i], m + 1, 1);
         y = fma((double)m, f.d[i], y);
         y = y + ci;
         k = last + 1;
@@ -998,9 +1013,19 @@ GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fil
     if (!ok || j >= nt || !(y >= dlen)) return false;       // (the period must end in the tail)
     // ---- second wrap and tail
     y = y - dlen;
-    for (int t = nt - j; t > 0; t--) y = y + ci;
+    for (int t = nt - j; t > 0; t--) {
+        emit(nt - t, y, 0.0, 1, 2);
+        y = y + ci;
+    }
     *remcode_out = y - P.smaxci;
     return true;
+}
+
+template <class Fill>
+GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out)
+{
+    GcNoEmit ne;
+    return gc_code_period(P, remcode, nt, fill, remcode_out, ne);
 }
 
 // Carrier NCO of one period (ref src/sdrcmn.c:649-668): phase remainder in, phase remainder out.
@@ -1010,16 +1035,16 @@ struct GcCarPlan {
     double ydpi;            // RN(1/DPI)
 };
 
-GC_HD void gc_car_plan_init(GcCarPlan &P, double ps)
+GC_HD void gc_car_plan_init(GcCarPlan &P, double ps, bool with_inv = true, bool with_prem = true)
 {
     GC_FP_STRICT
-    gc_fast_init(P.f, ps);
-    gc_fast_init(P.fprem, -GC_NCO_DPI);
+    gc_fast_init(P.f, ps, with_inv);
+    if (with_prem) gc_fast_init(P.fprem, -GC_NCO_DPI);
     P.ydpi = 1.0 / GC_NCO_DPI;
 }
 
-template <class Fill>
-GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fill, double *remcarr_out)
+template <class Fill, class Emit>
+GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fill, double *remcarr_out, Emit &emit)
 {
     GC_FP_STRICT
     const GcNcoFast &f = P.f;
@@ -1029,12 +1054,16 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
     int k = 0;
     bool done = false;
     if ((int)((gc_d2u(x) >> 52) & 0x7FF) >= f.ex0 + GC_NB) {
-        if (!gc_one_binade_walk(x, s, n, &x)) return false;
+        const double x0 = x;
+        double d1;
+        if (!gc_one_binade_walk(x, s, n, &x, &d1)) return false;
+        emit(0, x0, d1, n);
         done = true;
     }
     if (!done) {
         // next to zero: the reference's own additions (a channel fresh out of acquisition starts at phase 0)
         for (int t = 0; t < 8 && k < n && (x == 0.0 || (int)((gc_d2u(x) >> 52) & 0x7FF) < f.ex0); t++) {
+            emit(k, x, 0.0, 1);
             x = x + s;
             k += 1;
         }
@@ -1060,12 +1089,16 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
                 last = last > c.n - 1 ? c.n - 1 : last;
                 int m = last - kk;
                 ok = ok && m >= 0;
+                int kb = kk;
                 if ((f.tie >> i) & 1) {
                     const bool odd = (gc_d2u(x) & 1) && m > 0;
+                    if (odd) emit(k + kb, x, 0.0, 1);
                     const double xl = x + s;
                     x = odd ? xl : x;
                     m -= odd ? 1 : 0;
+                    kb += odd ? 1 : 0;
                 }
+                if (m >= 0) emit(k + kb, x, f.d[i], m + 1);
                 x = fma((double)m, f.d[i], x);
                 x = x + s;
                 kk = last + 1;
@@ -1080,6 +1113,13 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
     else while (p > GC_NCO_DPI) p = p - GC_NCO_DPI;
     *remcarr_out = p;
     return true;
+}
+
+template <class Fill>
+GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fill, double *remcarr_out)
+{
+    GcNoEmit ne;
+    return gc_carrier_period(P, remcarr, n, fill, remcarr_out, ne);
 }
 
 #if defined(__HIPCC__)

@@ -628,41 +628,18 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
     return v;
 }
 
+// One (channel, period) unit [or a long period's share `seg` of it] on one 256-lane workgroup: the body of
+// trk_corr_ps_kernel, also called period by period from the closed-loop kernel.  smem: PsLayout bytes.
+// Every lane of the workgroup must call it (it synchronises the workgroup).
 template <int DTYPE, int NTAP, int NIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 13 ? 3 : (NTAP <= 21 ? 2 : 1)), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
-                                                          const GcTrkUnit *__restrict__ unit,
-                                                          const GcUnitSegs *__restrict__ segs,
-                                                          const GcRound *__restrict__ rounds,
-                                                          int *__restrict__ partial, int nch, int nepoch, int nseg,
-                                                          int ntap_stride, int ntap_lo, int max_n, int rpw,
-                                                          int ablate)
+__device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, const GcUnitSegs *__restrict__ gs,
+                                        const GcRound *__restrict__ myrounds, int *__restrict__ pout, int ntap_stride,
+                                        int max_n, int rpw, int seg, int ablate, char *smem, int tid)
 {
     using L = PsLayout<DTYPE, NIT>;
-    // static, so that every LDS address is a compile-time offset
-    __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
     constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, LPAD = L::LPAD;
-    const int tid = threadIdx.x;
-    const int per_epoch = nch * nseg;
-    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int e = (qq / per_epoch) * 8 + slot, rr = qq % per_epoch;
-    const int ch = rr / nseg, seg = rr % nseg;
-    if (e >= nepoch) return;
-#ifdef GC_TRK_TRACE
-    unsigned long long *tr = nullptr;
-    if ((tid == 0 || tid == 192) && (blockIdx.x % 15) == 0 && blockIdx.x / 15 < GC_TRACE_N / 2) {
-        tr = gc_trk_trace + ((blockIdx.x / 15) * 2 + (tid != 0)) * 12;
-        tr[8] = wall_clock64();
-        tr[11] = blockIdx.x;
-    }
-#endif
-    GC_STAMP(0);
-    const GcChan &c = chan[ch];
     const int ntap = c.ntap;
-    if (c.dtype != DTYPE || ntap > NTAP || ntap <= ntap_lo) return;
-
-    const GcTrkUnit u = unit[(size_t)ch * nepoch + e];
     const int n = u.n, smax = c.smax, clen = c.clen, head = u.head, G = u.G;
-    int *pout = partial + (((size_t)ch * nepoch + e) * nseg + seg) * 2 * ntap_stride;
     const int g0 = seg * RGRP * rpw;
     // nothing to correlate (trk_expand: outside the reference's scratch, undefined chip step, NCO table
     // overflow) or nothing left for this workgroup
@@ -673,7 +650,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     const int klo = (g0 * 16 - head) / DTYPE;       // first sample index of the workgroup (may be < 0)
     int nround = (G - g0 + RGRP - 1) / RGRP;
     if (nround > rpw) nround = rpw;
-    GC_STAMP(1);
 
     constexpr int LUTPOS = L::LUTPOS;
     uint2 *lut = reinterpret_cast<uint2 *>(smem);
@@ -714,7 +690,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     };
     uint4 vA[NIT], vB[NIT];
     load_round(0, vA);                                  // in flight while the tables are set up
-    GC_STAMP(2);
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
     // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
@@ -725,8 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)(code + 3072);
     const int nedge = c.nedge;
     const int ncar = u.ncar, ncode = u.ncode;
-    {
-        const GcUnitSegs *gs = segs + ((size_t)ch * nepoch + e);
+    if (gs) {           // (the closed-loop kernel's planner writes the tables straight into the LDS image)
         if (tid < ncar) { sk0[tid] = gs->carK0[tid]; scar[tid] = gs->car[tid]; }
         if (tid == ncar) sk0[tid] = 0x7fffffff;
         if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = gs->code[tid - 64];
@@ -761,7 +735,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
     }
     int wseg = 0;                                       // wave-uniform: carrier piece of the wave's first sample
-    const GcRound *myrounds = rounds + (((size_t)ch * nepoch + e) * nseg + seg) * GC_MAXR;
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
     auto edge_js = [&](int ed, int w, int hint) -> int { // start position of the chip the list entry names
         // B = min{j : T(j) >= m in code period w}, T = the reference's truncated running sum.  The code
@@ -805,7 +778,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         // hoisted out of the loop over rounds into registers that would then spill
         int tl = tid;
         asm volatile("" : "+v"(tl));
-        if (r == 1) GC_STAMP(2);
         if (r + 1 < nround) load_round(r + 1, vnext);
         const GcRound ro = myrounds[r];
         const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0, rhint = ro.hint;
@@ -897,9 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
             }
         }
         lbase[tl] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
-        if (r == 1) GC_STAMP(3);
         __syncthreads();
-        if (r == 1) GC_STAMP(4);
         {
             const int2 tv = *reinterpret_cast<const int2 *>(&wp[8]);
             const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
@@ -907,7 +877,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
             finQ += (unsigned)rlast * (unsigned)tq;
             if (tl < 16) wpre[((r + 1) & 1) * 16 + tl] = 0;   // the other copy, for the next round
         }
-        if (r == 1) GC_STAMP(5);
 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
         // (taps past ntap repeat tap 0 and are never written out; the +-1 code variant adds or
@@ -946,9 +915,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
-        if (r == 1) GC_STAMP(6);
         if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
-        if (r == 1) GC_STAMP(1);
     };
     for (int r = 0; r < nround; r += 2) {
         round(r, vA, vB);
@@ -978,9 +945,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
         pout[tid] = (int)(si + finI);
         pout[ntap_stride + tid] = (int)(sq + finQ);
     }
-#ifdef GC_TRK_TRACE
-    if (tr) { tr[7] = __builtin_readcyclecounter(); tr[9] = wall_clock64(); }
-#endif
+}
+
+template <int DTYPE, int NTAP, int NIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 13 ? 3 : (NTAP <= 21 ? 2 : 1)), 8))) void trk_corr_ps_kernel(const GcChan *__restrict__ chan,
+                                                          const GcTrkUnit *__restrict__ unit,
+                                                          const GcUnitSegs *__restrict__ segs,
+                                                          const GcRound *__restrict__ rounds,
+                                                          int *__restrict__ partial, int nch, int nepoch, int nseg,
+                                                          int ntap_stride, int ntap_lo, int max_n, int rpw,
+                                                          int ablate)
+{
+    using L = PsLayout<DTYPE, NIT>;
+    // static, so that every LDS address is a compile-time offset
+    __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
+    // Workgroup order (speed only, never correctness): blocks b and b+8 tend to share an XCD, so every 8th
+    // block walks one epoch's channels back to back -- the epoch's IF window is then fetched from HBM once
+    // and served to the other channels by that XCD's L2.
+    const int tid = threadIdx.x;
+    const int per_epoch = nch * nseg;
+    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int e = (qq / per_epoch) * 8 + slot, rr = qq % per_epoch;
+    const int ch = rr / nseg, seg = rr % nseg;
+    if (e >= nepoch) return;
+    const GcChan &c = chan[ch];
+    const int ntap = c.ntap;
+    if (c.dtype != DTYPE || ntap > NTAP || ntap <= ntap_lo) return;
+    const size_t ui = (size_t)ch * nepoch + e;
+    const GcTrkUnit u = unit[ui];
+    ps_unit<DTYPE, NTAP, NIT>(c, u, segs + ui, rounds + (ui * nseg + seg) * GC_MAXR, partial + (ui * nseg + seg) * 2 * ntap_stride,
+                              ntap_stride, max_n, rpw, seg, ablate, smem, tid);
 }
 
 // Sums the segment partials of every (channel, epoch) into the correlator
@@ -1032,6 +1026,300 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(const int *__restrict__
         else sumQ[ch * ntap + (tid - ntap)] = (double)tot * (1.0 / 32.0);
     }
     if (tid == 0) __hip_atomic_store(&sc[SS - 1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------
+// closed loop: what sdrthread() does around sdrtracking() (ref src/sdrmain.c:264-312)
+// ---------------------------------------------------------------------------
+// ref src/sdrtrk.c:95-126 (IP = sumI[0], QP = sumQ[0] after the II/QQ swap of :42)
+__device__ __forceinline__ void loop_pll(gnsscorr_loop_t *L, GcTrkState &st, int prm, double dt)
+{
+    GC_FP_STRICT
+    const double PI = 3.1415926535897932;
+    const double IP = L->sumI[0], QP = L->sumQ[0], oldIP = L->oldsumI[0], oldQP = L->oldsumQ[0];
+    double carrErr;
+    if (IP > 0) carrErr = atan2(QP, IP) / PI;
+    else carrErr = atan2(-QP, -IP) / PI;
+    const double f1 = (IP == 0) ? PI / 2 : atan(QP / IP);
+    const double f2 = (oldIP == 0) ? PI / 2 : atan(oldQP / oldIP);
+    double freqErr = f1 - f2;
+    if (freqErr > PI / 2) freqErr = PI - freqErr;
+    if (freqErr < -PI / 2) freqErr = -PI - freqErr;
+    L->carrNco += L->pllaw[prm] * (carrErr - L->carrErr) + L->pllw2[prm] * dt * carrErr + L->fllw[prm] * dt * freqErr;
+    st.carrfreq = L->acqfreq + L->carrNco;
+    L->carrErr = carrErr;
+    L->freqErr = freqErr;
+}
+
+// ref src/sdrtrk.c:135-150
+__device__ __forceinline__ void loop_dll(gnsscorr_loop_t *L, GcTrkState &st, int prm, double dt)
+{
+    GC_FP_STRICT
+    const double IE = L->sumI[L->ne], IL = L->sumI[L->nl], QE = L->sumQ[L->ne], QL = L->sumQ[L->nl];
+    const double codeErr = (sqrt(IE * IE + QE * QE) - sqrt(IL * IL + QL * QL)) /
+                           (sqrt(IE * IE + QE * QE) + sqrt(IL * IL + QL * QL));
+    L->codeNco += L->dllaw[prm] * (codeErr - L->codeErr) + L->dllw2[prm] * dt * codeErr;
+    st.codefreq = L->crate - L->codeNco + (st.carrfreq - L->f_if - L->foffset) / (L->f_cf / L->crate);
+    L->codeErr = codeErr;
+}
+
+// emitters that fill the correlator's LDS tables in place (lane-uniform calls from the planning wavefront)
+struct LdsCarTable {
+    int *k0;
+    GcCarSeg *seg;
+    int n, overflow;
+    __device__ void operator()(int k, double x, double d, int)
+    {
+        const GcCarSeg s = gc_carseg_make(x, d);
+        if (n > 0 && s.fx == 0 && s.dfx == 0 && seg[n - 1].fx == 0 && seg[n - 1].dfx == 0) return;
+        if (n >= GC_NCAR) { overflow = 1; return; }
+        k0[n] = k;
+        seg[n] = s;
+        n++;
+    }
+};
+
+#define GC_LOOP_MAXSEG 4        // workgroup shares of one period (16 rounds each): periods up to 262144 samples
+
+// One workgroup per channel walks its code periods in order: plan (wavefront 0: NCO chain with the piece
+// tables written straight into the correlator's LDS image) -> correlate (the whole workgroup, ps_unit) ->
+// sums, cumsumcorr and -- when the reference's cadence says so -- pll/dll (wavefront 0), which set the
+// frequencies of the next period.  No host round trip between periods.
+template <int DTYPE, int NTAP, int NIT>
+__global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict__ chan, GcTrkState *__restrict__ state,
+                                                       gnsscorr_loop_t *__restrict__ loop, const uint64_t *__restrict__ wrpos,
+                                                       double *__restrict__ corrI, double *__restrict__ corrQ,
+                                                       int *__restrict__ nsamp_out, gnsscorr_trklog_t *__restrict__ log,
+                                                       int *__restrict__ ndone, int *__restrict__ nco_overflow, int nch,
+                                                       int nper, int nseg, int max_n, int rpw)
+{
+    using L = PsLayout<DTYPE, NIT>;
+    __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
+    __shared__ GcTrkUnit su;
+    __shared__ GcRound sr[GC_LOOP_MAXSEG][GC_MAXR];
+    __shared__ int spart[GC_LOOP_MAXSEG][2 * NTAP];
+    __shared__ int sgo;
+    __shared__ gnsscorr_loop_t slp;             // the channel's loop state while the kernel runs
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (ch >= nch) return;
+    const GcChan &c = chan[ch];
+    const int ntap = c.ntap;
+    if (c.dtype != DTYPE || ntap > NTAP) return;
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(loop + ch);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&slp);
+        for (int i = tid; i < (int)(sizeof(gnsscorr_loop_t) / 8); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    gnsscorr_loop_t *lp = &slp;
+    int *sk0 = reinterpret_cast<int *>(smem + L::K0_OFF);
+    GcCarSeg *scar = reinterpret_cast<GcCarSeg *>(smem + L::CAR_OFF);
+    GcCodeSeg *scode = reinterpret_cast<GcCodeSeg *>(smem + L::CODE_OFF);
+    const uint64_t wp = wrpos[ch];
+
+    // wavefront 0 keeps the chained state in registers
+    GcTrkState st = state[ch];
+    GcCodePlan PC;
+    GcCarPlan PK;
+    GcFillLanes fill{lane};
+    double lastcarr = 0.0, lastcode = 0.0;
+    bool have_plan = false;
+    if (wave == 0) gc_fast_init(PK.fprem, -GC_NCO_DPI);
+    int p = 0;
+    for (; p < nper; p++) {
+        if (wave == 0) {
+            // ---- is the period there yet?  ref src/sdrtrk.c:26-30
+            const uint64_t bufflocnow = wp - (uint64_t)c.nsamp;
+            const bool go = bufflocnow > st.buffloc;
+            if (go) {
+                if (!have_plan || st.carrfreq != lastcarr || st.codefreq != lastcode) {     // new frequencies: new step tables
+                    const double ci0 = __dmul_rn(c.ti, st.codefreq);
+                    gc_code_plan_init(PC, ci0, c.clen, c.smax, false);
+                    gc_car_plan_init(PK, gc_carrier_ps(st.carrfreq, c.ti), false, false);
+                    lastcarr = st.carrfreq;
+                    lastcode = st.codefreq;
+                    have_plan = true;
+                }
+                const double ci = PC.f.s, dlen = (double)c.clen;
+                const double q = __ddiv_rn(__dsub_rn(dlen, st.remcode), __ddiv_rn(st.codefreq, c.f_sf));   // ref :31-32
+                int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
+                const int nt = n + 2 * c.smax;
+                GcTrkUnit u;
+                const uint64_t a0 = (st.buffloc % c.ringlen) * (uint64_t)DTYPE;
+                u.a_al = a0 & ~(uint64_t)15;
+                u.head = (int)(a0 - u.a_al);
+                u.n = n;
+                u.G = (u.head + n * DTYPE + 15) >> 4;
+                u.nt = nt;
+                u.ncar = u.ncode = 0;
+                double remcarr = st.remcarr, remcode = st.remcode;
+                const bool valid = n > 0 && n <= max_n && ci > 0.0 && ci < dlen;
+                if (valid) {
+                    LdsCarTable ct{sk0, scar, 0, 0};
+                    GcCodeTable dt{scode, GC_NCODE, 0, 0};
+                    double r;
+                    if (gc_carrier_period(PK, st.remcarr, n, fill, &r, ct)) {
+                        remcarr = r;
+                    } else {            // any other shape: the general walkers
+                        ct.n = 0;
+                        ct.overflow = 0;
+                        gc_fast_init(PK.f, PK.f.s);
+                        const double xn = gc_fast_carrier_walk(PK.f, gc_carrier_phis(st.remcarr), n, ct);
+                        remcarr = gc_fast_prem(PK.fprem, xn);
+                    }
+                    if (gc_code_period(PC, st.remcode, nt, fill, &r, dt)) {
+                        remcode = r;
+                    } else {
+                        dt.n = 0;
+                        dt.overflow = 0;
+                        gc_fast_init(PC.f, ci);
+                        const double cend = gc_fast_code_walk(PC.f, gc_code_start(st.remcode, c.smax, ci, c.clen), c.clen, nt, dt);
+                        remcode = gc_code_rem(cend, c.smax, ci);
+                    }
+                    u.ncar = ct.n;
+                    u.ncode = dt.n;
+                    if (ct.overflow || dt.overflow) {
+                        if (lane == 0) atomicAdd(nco_overflow, 1);
+                        u.n = 0;
+                    }
+                    if (lane == 0) sk0[ct.n < GC_NCAR ? ct.n : GC_NCAR] = 0x7fffffff;
+                } else {
+                    u.n = 0;
+                }
+                // rounds: lane (seg, r)
+                if (u.n > 0) {
+                    const int rgrp = L::RGRP, rsamp = L::RSAMP;
+                    const int sg = lane / GC_MAXR, r = lane % GC_MAXR;
+                    const int g0 = sg * rgrp * rpw;
+                    if (sg < nseg && sg < GC_LOOP_MAXSEG && r < rpw && g0 + r * rgrp < u.G) {
+                        const unsigned short *rank = (const unsigned short *)(c.code + 1024);
+                        const int klo = (g0 * 16 - u.head) / DTYPE;
+                        const int kl = klo + r * rsamp;
+                        const int kfirst = kl > 0 ? kl : 0;
+                        const int kend = (kl + rsamp < n ? kl + rsamp : n);
+                        int wa = 0, wb = 0, hint = 0;
+                        const int ma = gc_code_chip_at(scode, u.ncode, kfirst, &wa, &hint);
+                        const int mb = gc_code_chip_at(scode, u.ncode, kend - 1 + 2 * c.smax, &wb, nullptr);
+                        GcRound ro;
+                        ro.q0 = wa * c.nedge + (int)rank[ma];
+                        ro.q1 = wb * c.nedge + (int)rank[mb];
+                        ro.clast = (short)c.code[mb];
+                        ro.w0 = (short)wa;
+                        ro.hint = hint;
+                        sr[sg][r] = ro;
+                    }
+                }
+                if (lane == 0) {
+                    su = u;
+                    gnsscorr_trklog_t *lg = log + (size_t)ch * nper + p;
+                    lg->buffloc = st.buffloc;
+                    lg->currnsamp = n;
+                    nsamp_out[(size_t)ch * nper + p] = n;
+                }
+                st.remcarr = remcarr;
+                st.remcode = remcode;
+                st.buffloc += (uint64_t)(int64_t)n;
+            }
+            if (lane == 0) sgo = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (!sgo) break;
+        // ---- correlate: the whole workgroup, one share of the period after the other
+        for (int sg = 0; sg < nseg && sg < GC_LOOP_MAXSEG; sg++) {
+            ps_unit<DTYPE, NTAP, NIT>(c, su, (const GcUnitSegs *)nullptr, sr[sg], spart[sg], NTAP, max_n, rpw, sg, 0, smem, tid);
+            __syncthreads();
+        }
+        // ---- outputs, cumsumcorr, loop filters (ref src/sdrtrk.c:35-36,42,64-86; src/sdrmain.c:269-310)
+        if (wave == 0) {
+            if (lane < ntap) {
+                int sI = 0, sQ = 0;
+                for (int sg = 0; sg < nseg && sg < GC_LOOP_MAXSEG; sg++) { sI += spart[sg][lane]; sQ += spart[sg][NTAP + lane]; }
+                const double cI = (double)sI * (1.0 / 32.0), cQ = (double)sQ * (1.0 / 32.0);     // correlator's II, QQ (ref src/sdrcmn.c:716-719)
+                corrI[((size_t)ch * nper + p) * ntap + lane] = cI;
+                corrQ[((size_t)ch * nper + p) * ntap + lane] = cQ;
+                // memcpy(oldI, II, 1 + 2*corrn*sizeof(double)): the last tap only gets its lowest byte (ref :35-36)
+                const double pII = lp->II[lane], pQQ = lp->QQ[lane];
+                double oI = pII, oQ = pQQ;
+                if (lane == ntap - 1) {
+                    oI = gc_u2d((gc_d2u(lp->oldI[lane]) & ~0xFFull) | (gc_d2u(pII) & 0xFFull));
+                    oQ = gc_u2d((gc_d2u(lp->oldQ[lane]) & ~0xFFull) | (gc_d2u(pQQ) & 0xFFull));
+                }
+                lp->oldI[lane] = oI;
+                lp->oldQ[lane] = oQ;
+                // correlator(..., trk.QQ, trk.II, ...): trk.II <- sum dataQ*code, trk.QQ <- sum dataI*code (ref :42)
+                lp->II[lane] = cQ;
+                lp->QQ[lane] = cI;
+                // cumsumcorr, polarity +1 (ref :64-76)
+                lp->oldsumI[lane] = __dadd_rn(lp->oldsumI[lane], oI);
+                lp->oldsumQ[lane] = __dadd_rn(lp->oldsumQ[lane], oQ);
+                lp->sumI[lane] = __dadd_rn(lp->sumI[lane], cQ);
+                lp->sumQ[lane] = __dadd_rn(lp->sumQ[lane], cI);
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            // loop timing of sdrnavigation()/checkbit() (ref src/sdrnav.c:18,241-262)
+            int flag = 0;
+            const int flagsync = lp->flagsync;
+            int navcnt = lp->navcnt, swloop = lp->swloop;
+            const uint64_t cnt = lp->cnt;
+            if (flagsync) {
+                const int biti = (int)(cnt % (uint64_t)lp->rate);
+                const int diffi = biti - lp->synci;
+                if (diffi == 1 || diffi == -lp->rate + 1) navcnt = 1;
+                swloop = (navcnt % lp->loopms == 0);
+                navcnt++;
+            }
+            if (lane == 0) {
+                if (!flagsync) {
+                    loop_pll(lp, st, 0, lp->ctime);
+                    loop_dll(lp, st, 0, lp->ctime);
+                    flag = 1;
+                } else if (swloop) {
+                    loop_pll(lp, st, 1, (double)lp->loopms / 1000);
+                    loop_dll(lp, st, 1, (double)lp->loopms / 1000);
+                    flag = 2;
+                }
+                gnsscorr_trklog_t *lg = log + (size_t)ch * nper + p;
+                lg->carrfreq = st.carrfreq;
+                lg->codefreq = st.codefreq;
+                lg->carrErr = lp->carrErr;
+                lg->codeErr = lp->codeErr;
+                lg->carrNco = lp->carrNco;
+                lg->codeNco = lp->codeNco;
+                lg->freqErr = lp->freqErr;
+                lg->remcode = st.remcode;
+                lg->remcarr = st.remcarr;
+                lg->flagloopfilter = flag;
+                lp->navcnt = navcnt;
+                lp->swloop = swloop;
+                lp->cnt = cnt + 1;
+            }
+            // the new frequencies, for every lane of the planning wavefront
+            flag = __builtin_amdgcn_readfirstlane(flag);
+            st.carrfreq = gc_u2d(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gc_d2u(st.carrfreq) >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)gc_d2u(st.carrfreq)));
+            st.codefreq = gc_u2d(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gc_d2u(st.codefreq) >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)gc_d2u(st.codefreq)));
+            if (flag && lane < ntap) {      // clearcumsumcorr (ref src/sdrtrk.c:77-86)
+                lp->oldsumI[lane] = 0.0;
+                lp->oldsumQ[lane] = 0.0;
+                lp->sumI[lane] = 0.0;
+                lp->sumQ[lane] = 0.0;
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (tid == 0) {
+        state[ch] = st;
+        ndone[ch] = p;
+    }
+    __syncthreads();
+    {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(loop + ch);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&slp);
+        for (int i = tid; i < (int)(sizeof(gnsscorr_loop_t) / 8); i += 256) dst[i] = src[i];
+    }
 }
 
 int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8); 0 = not yet chosen
@@ -1164,6 +1452,40 @@ int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit
     if (dtype == 1)
         return launch_corr_taps<1>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
     return gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
+}
+
+template <int DTYPE>
+int launch_loop_taps(hipStream_t st, const GcChan *chan, GcTrkState *state, gnsscorr_loop_t *loop, const uint64_t *wrpos,
+                     double *corrI, double *corrQ, int *nsamp_out, gnsscorr_trklog_t *log, int *ndone, int *nco_overflow,
+                     int nch, int nper, int nseg, int ntap, int max_n)
+{
+    constexpr int NIT = DTYPE == 1 ? 1 : 2;
+    const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
+#define GC_LL(N) do { hipLaunchKernelGGL((trk_loop_kernel<DTYPE, N, NIT>), dim3(nch), dim3(256), 0, st, chan, state, loop, wrpos, \
+                                         corrI, corrQ, nsamp_out, log, ndone, nco_overflow, nch, nper, nseg, max_n, rpw); \
+                      GC_HIP(hipGetLastError()); return 0; } while (0)
+    if (ntap <= 3) GC_LL(3);
+    if (ntap <= 5) GC_LL(5);
+    if (ntap <= 7) GC_LL(7);
+    if (ntap <= 13) GC_LL(13);
+    if (ntap <= 21) GC_LL(21);
+    GC_LL(33);
+#undef GC_LL
+}
+
+// closed loop: nper periods of every channel of this dtype (one launch per dtype present)
+int gc_launch_trk_loop(hipStream_t st, const GcChan *chan, GcTrkState *state, gnsscorr_loop_t *loop, const uint64_t *wrpos,
+                       double *corrI, double *corrQ, int *nsamp_out, gnsscorr_trklog_t *log, int *ndone, int *nco_overflow,
+                       int nch, int nper, int nseg, int dtype, int ntap, int max_n, int smax_max)
+{
+    trk_pick_nit();
+    if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_loop: tap offset %d samples (<= 64 supported)", smax_max);
+    if (nseg > GC_LOOP_MAXSEG) return gc_fail(GNSSCORR_EINVAL, "trk_loop: period of %d samples too long", max_n);
+    if (dtype == 2)
+        return launch_loop_taps<2>(st, chan, state, loop, wrpos, corrI, corrQ, nsamp_out, log, ndone, nco_overflow, nch, nper, nseg, ntap, max_n);
+    if (dtype == 1)
+        return launch_loop_taps<1>(st, chan, state, loop, wrpos, corrI, corrQ, nsamp_out, log, ndone, nco_overflow, nch, nper, nseg, ntap, max_n);
+    return gc_fail(GNSSCORR_EINVAL, "trk_loop: dtype %d not 1 or 2", dtype);
 }
 
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,

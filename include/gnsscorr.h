@@ -133,6 +133,55 @@ int  gnsscorr_trk_fetch_sums(gnsscorr_ctx *ctx, double *sumI, double *sumQ);
  * every gnsscorr_trk_run issued before it */
 int  gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ);
 
+/* ---- tracking, closed loop: cumsumcorr() + pll() + dll() on the device -------
+ * What sdrthread() does around sdrtracking() every code period (ref
+ * src/sdrmain.c:264-312): accumulate the correlator outputs (ref
+ * src/sdrtrk.c:64-76), run the loop filters -- every period with prm1 until the
+ * nav bit is synchronised, then whenever checkbit() raises swloop (every loopms
+ * periods counted from the bit edge, ref src/sdrnav.c:241-262) with prm2 -- and
+ * clear the sums after each filter update.  The loop state lives on the device
+ * next to the NCO state; a run of N periods needs no host round trip.
+ * Bit synchronisation itself (checksync(), ref src/sdrnav.c:198-233) stays with
+ * the caller's nav module: it reports flagsync/synci through gnsscorr_loop_set. */
+typedef struct {
+    double acqfreq;                         /* ref sdracq_t.acqfreq                   */
+    double f_if, foffset, f_cf, crate, ctime;   /* ref sdrch_t                        */
+    double pllaw[2], pllw2[2], fllw[2];     /* ref sdrtrkprm_t of prm1 [0], prm2 [1]  */
+    double dllaw[2], dllw2[2];
+    int    ne, nl;                          /* ref sdrtrk_t.ne / .nl                  */
+    int    loopms;                          /* ref sdrtrk_t.loopms                    */
+    int    rate;                            /* ref sdrnav_t.rate                      */
+    int    flagsync, synci;                 /* ref sdrnav_t.flagsync / .synci         */
+    int    navcnt, swloop;                  /* ref sdrnav_t.cnt / .swloop (checkbit)  */
+    uint64_t cnt;                           /* ref sdrthread's cnt: periods tracked   */
+    double carrNco, codeNco, carrErr, codeErr, freqErr;     /* ref sdrtrk_t           */
+    double II[GNSSCORR_MAXTAPS], QQ[GNSSCORR_MAXTAPS];      /* ref sdrtrk_t (all 8)   */
+    double oldI[GNSSCORR_MAXTAPS], oldQ[GNSSCORR_MAXTAPS];
+    double sumI[GNSSCORR_MAXTAPS], sumQ[GNSSCORR_MAXTAPS];
+    double oldsumI[GNSSCORR_MAXTAPS], oldsumQ[GNSSCORR_MAXTAPS];
+} gnsscorr_loop_t;
+
+int  gnsscorr_loop_set(gnsscorr_ctx *ctx, int ch0, int nch, const gnsscorr_loop_t *lp);
+int  gnsscorr_loop_get(gnsscorr_ctx *ctx, int ch0, int nch, gnsscorr_loop_t *lp);
+
+/* One row per code period, the columns writelog() prints (ref src/sdrout.c:412-437) */
+typedef struct {
+    double carrfreq, codefreq;              /* after this period's filter update      */
+    double carrErr, codeErr, carrNco, codeNco, freqErr;
+    double remcode, remcarr;                /* after this period                      */
+    uint64_t buffloc;                       /* first sample of this period            */
+    int    currnsamp;
+    int    flagloopfilter;                  /* 0 none, 1 prm1, 2 prm2                 */
+} gnsscorr_trklog_t;
+
+/* Track `nperiod` code periods of every channel closed loop.  A channel stops early
+ * where sdrtracking() would find no data yet (ref src/sdrtrk.c:26-30: bufflocnow
+ * <= buffloc).  Asynchronous; results by gnsscorr_trk_fetch (II/QQ per period,
+ * periods not run are zero with nsamp_out 0) and gnsscorr_trk_fetch_log. */
+int  gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod);
+/* log[nch][nperiod] of the last gnsscorr_trk_run_loop; ndone[nch] = periods run */
+int  gnsscorr_trk_fetch_log(gnsscorr_ctx *ctx, gnsscorr_trklog_t *log, int *ndone);
+
 /* ---- acquisition: parallel code phase search --------------------------------
  * For every channel: up to `intg` iterations of pcorrelator() (ref
  * src/sdrcmn.c:738-773) over the channel's Doppler grid, accumulated

@@ -523,6 +523,7 @@ int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
         if (ch->corrp[i] == corrp) { ch->ne = 2 * (i + 1) - 1; ch->nl = 2 * (i + 1); }
     }
     ch->loopms = (ctype == ORC_CTYPE_L1SBAS ? 2 : 10) * (int)(ch->ctime * 1000);
+    ch->rate = ctype == ORC_CTYPE_G1 ? 10 : (ctype == ORC_CTYPE_L1SBAS ? 2 : 20);   /* NAVRATE_*, ref src/sdr.h:159-171 */
     for (i = 0; i < 2; i++) {
         ch->dllw2[i] = (dllb[i] / 0.53) * (dllb[i] / 0.53);
         ch->dllaw[i] = 1.414 * (dllb[i] / 0.53);
@@ -642,4 +643,35 @@ void orc_dll(orc_chan_t *ch, int prm, double dt)
     ch->codefreq = ch->crate - ch->codeNco +
                    (ch->carrfreq - ch->f_if - ch->foffset) / (ch->f_cf / ch->crate);
     ch->codeErr = codeErr;
+}
+
+/* ref src/sdrmain.c:264-312 with the timing lines of src/sdrnav.c:18-20 (biti) and :241-262 (checkbit:
+ * counter reset at the bit edge, swloop every loopms counts); nav.ocode is all ones (src/sdrinit.c:520-521) */
+int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc)
+{
+    orc_sdrtracking(ch, ring, *buffloc);
+    if (!ch->flagtrk) return 0;
+    /* sdrnavigation() is called from sdrtracking() after the correlator (src/sdrtrk.c:46) */
+    if (ch->flagsync) {
+        int biti = (int)(ch->cnt % (uint64_t)ch->rate);
+        int diffi = biti - ch->synci;
+        if (diffi == 1 || diffi == -ch->rate + 1) ch->navcnt = 1;
+        ch->swloop = (ch->navcnt % ch->loopms == 0);
+        ch->navcnt++;
+    }
+    orc_cumsumcorr(ch, 1);
+    ch->flagloopfilter = 0;
+    if (!ch->flagsync) {
+        orc_pll(ch, 0, ch->ctime);
+        orc_dll(ch, 0, ch->ctime);
+        ch->flagloopfilter = 1;
+    } else if (ch->swloop) {
+        orc_pll(ch, 1, (double)ch->loopms / 1000);
+        orc_dll(ch, 1, (double)ch->loopms / 1000);
+        ch->flagloopfilter = 2;
+    }
+    if (ch->flagloopfilter) orc_clearcumsumcorr(ch);
+    ch->cnt++;
+    *buffloc += (uint64_t)ch->currnsamp;
+    return 1;
 }

@@ -128,6 +128,9 @@ typedef struct {
     int    currnsamp;
     /* loop parameters (ref src/sdrinit.c:402-425) */
     double dllw2[2], dllaw[2], pllw2[2], pllaw[2], fllw[2];
+    /* nav timing that schedules the loop filters (ref src/sdrnav.c:18-31,241-262) + thread counter */
+    int    rate, flagsync, synci, navcnt, swloop, flagloopfilter;
+    uint64_t cnt;
 } orc_chan_t;
 
 /* ref src/sdrinit.c:583-657 (+ :385-394, :402-480); xcode left NULL */
@@ -147,6 +150,11 @@ void orc_clearcumsumcorr(orc_chan_t *ch);
 /* ref src/sdrtrk.c:95-150; prm = 0 (before nav sync) or 1 (after) */
 void orc_pll(orc_chan_t *ch, int prm, double dt);
 void orc_dll(orc_chan_t *ch, int prm, double dt);
+/* One pass of sdrthread()'s tracking branch (ref src/sdrmain.c:264-312): sdrtracking incl. the loop
+ * timing part of sdrnavigation/checkbit (ref src/sdrnav.c:18-20,241-262; bit sync itself is an input:
+ * ch->flagsync/synci), cumsumcorr, pll/dll per the flagsync/swloop cadence, clearcumsumcorr, cnt++,
+ * *buffloc += currnsamp.  Returns ch->flagtrk. */
+int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc);
 
 #ifdef __cplusplus
 }

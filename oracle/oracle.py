@@ -34,7 +34,9 @@ class Chan(C.Structure):
                 [(n, C.c_double * MAXTAPS) for n in ("II", "QQ", "oldI", "oldQ", "sumI", "sumQ", "oldsumI",
                                                      "oldsumQ")] +
                 [("currnsamp", C.c_int)] +
-                [(n, C.c_double * 2) for n in ("dllw2", "dllaw", "pllw2", "pllaw", "fllw")])
+                [(n, C.c_double * 2) for n in ("dllw2", "dllaw", "pllw2", "pllaw", "fllw")] +
+                [(n, C.c_int) for n in ("rate", "flagsync", "synci", "navcnt", "swloop", "flagloopfilter")] +
+                [("cnt", C.c_uint64)])
 
 
 _lib = None
@@ -82,6 +84,7 @@ def lib():
     L.orc_clearcumsumcorr.argtypes = [C.POINTER(Chan)]
     L.orc_pll.argtypes = [C.POINTER(Chan), i, d]
     L.orc_dll.argtypes = [C.POINTER(Chan), i, d]
+    L.orc_sdrthread_step.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 

@@ -128,6 +128,32 @@ int nco_carrier_period(double ti, double freq, double remcarr, int n, double *pr
     return gc_carrier_period(P, remcarr, n, fill, prem) ? 1 : 0;
 }
 
+// period steps with table emission (what the closed-loop kernel runs): every index from the tables
+int nco_period_tables(double ti, double freq, double remcarr, double codefreq, int len, double remcode, int smax, int n,
+                      int *idx, int *chip, double *prem, double *rem)
+{
+    int k0[GC_NB * 3];
+    GcCarSeg cseg[GC_NB * 3];
+    GcCodeSeg dseg[GC_NB * 3];
+    GcCarTable ct{k0, cseg, GC_NB * 3, 0, 0};
+    GcCodeTable dt{dseg, GC_NB * 3, 0, 0};
+    GcCodePlan PC;
+    GcCarPlan PK;
+    gc_code_plan_init(PC, ti * codefreq, len, smax);
+    gc_car_plan_init(PK, gc_carrier_ps(freq, ti));
+    GcFillLoop fill;
+    int r = 0;
+    if (gc_carrier_period(PK, remcarr, n, fill, prem, ct) && !ct.overflow) {
+        r |= 1;
+        for (int k = 0; k < n; k++) idx[k] = gc_carrier_idx_at(k0, cseg, ct.n, k);
+    }
+    if (gc_code_period(PC, remcode, n + 2 * smax, fill, rem, dt) && !dt.overflow) {
+        r |= 2;
+        for (int j = 0; j < n + 2 * smax; j++) chip[j] = gc_code_chip_at(dseg, dt.n, j, nullptr);
+    }
+    return r;
+}
+
 // end values only (what the planner chains)
 void nco_chain(double phi0, double freq, double ti, int n, int len, double coff, int smax, double ci,
                double *prem, double *rem)

@@ -1,0 +1,133 @@
+"""Closed loop on the device (gnsscorr_trk_run_loop) vs the oracle's restatement of sdrthread()'s tracking
+branch (ref src/sdrmain.c:264-312: sdrtracking, cumsumcorr, pll, dll, clearcumsumcorr in the
+flagsync / swloop cadence of src/sdrnav.c:241-262).
+
+Bar: correlator sums, samples per period, the filter-update flags and the NCO remainders bit for bit over
+hundreds of periods; filter states and frequencies to 1e-12 relative (atan2/atan of the device maths
+library may differ from the host's in the last bit) -- and since every period's NCO tables are built
+from those frequencies, identical sums over hundreds of periods also say the frequencies stayed
+within a few ulps."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F_SF = 16.368e6
+
+
+def _signal(gc, synth, prns, dop, cph, nper, dtype=2, f_if=0.0, cn0=47.0, seed=41):
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in prns}
+    rng = np.random.default_rng(seed)
+    sats = [dict(prn=p, doppler=d, codephase=c, cn0=cn0, phase=0.4 * i, bits=rng.choice([-1.0, 1.0], size=64))
+            for i, (p, d, c) in enumerate(zip(prns, dop, cph))]
+    return synth.make_if(codes, 16368 * nper, f_sf=F_SF, f_if=f_if, dtype=dtype, sats=sats, seed=seed)
+
+
+def _close(a, b, tol=1e-12):
+    return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+
+
+def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, flagsync, chunks):
+    prns = [5, 12, 25, 30]
+    dop = [1517.0, -3222.0, 4630.0, -120.0]
+    cph = [311.3, 12.8, 870.1, 555.5]
+    sig = _signal(gc, synth, prns, dop, cph, nper + 3, dtype=dtype, f_if=f_if)
+    nsamples = sig.shape[0]
+    engine.ring_create(1, dtype, nsamples)
+    engine.ring_push_raw(1, sig, nsamples)
+    chans = [gc.Channel(p, dtype=dtype, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp) for p in prns]
+    engine.set_channels(chans)
+    L = orc.lib()
+    ring = orc.make_ring(sig, nsamples, nsamples)
+    ochs, bufflocs, states, loops = [], [], [], []
+    for i, c in enumerate(chans):
+        acqfreq = f_if + 200.0 * round(dop[i] / 200.0)          # the 200 Hz grid of sdracquisition()
+        o = orc.make_chan(c.prn, dtype=dtype, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
+        o.acq.acqfreq = acqfreq
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = acqfreq, c.crate, 0.0, 0.0
+        o.flagsync, o.synci, o.cnt = flagsync, (3 + 5 * i) % 20, 2001 + 7 * i
+        b = int(round((1023 - cph[i]) * 16)) % 16368
+        ochs.append(o)
+        bufflocs.append(C.c_uint64(b))
+        states.append(dict(carrfreq=acqfreq, codefreq=c.crate, remcode=0.0, remcarr=0.0, buffloc=b))
+        loops.append(engine.loop_state(i, acqfreq, flagsync=flagsync, synci=o.synci, cnt=o.cnt))
+    engine.trk_set_state(states)
+    engine.loop_set(loops)
+    done = 0
+    for nrun in chunks:                                         # several runs: the state must carry over
+        engine.trk_run_loop(nrun)
+        II, QQ, ns = engine.trk_fetch()
+        log, ndone = engine.trk_fetch_log()
+        assert np.all(ndone == nrun)
+        for i, o in enumerate(ochs):
+            for e in range(nrun):
+                assert L.orc_sdrthread_step(C.byref(o), C.byref(ring), C.byref(bufflocs[i])) == 1
+                ntap = 1 + 2 * corrn
+                where = (i, done + e)
+                assert ns[i, e] == o.currnsamp, where
+                # after the step the oracle's II/QQ hold this period's correlator outputs
+                assert np.array_equal(II[i, e], np.ctypeslib.as_array(o.II)[:ntap]), where
+                assert np.array_equal(QQ[i, e], np.ctypeslib.as_array(o.QQ)[:ntap]), where
+                r = log[i, e]
+                assert r["flagloopfilter"] == o.flagloopfilter, where
+                assert r["remcode"] == o.remcode and r["remcarr"] == o.remcarr, where
+                assert _close(r["carrfreq"], o.carrfreq) and _close(r["codefreq"], o.codefreq), where
+                assert _close(r["carrNco"], o.carrNco) and _close(r["codeNco"], o.codeNco), where
+                assert _close(r["carrErr"], o.carrErr) and _close(r["codeErr"], o.codeErr) and _close(r["freqErr"], o.freqErr), where
+        done += nrun
+    fin = engine.trk_get_state()
+    lst = engine.loop_get()
+    for i, o in enumerate(ochs):
+        assert fin[i]["buffloc"] == bufflocs[i].value and fin[i]["remcode"] == o.remcode and fin[i]["remcarr"] == o.remcarr
+        assert lst[i].cnt == o.cnt and lst[i].navcnt == o.navcnt
+        ntap = 1 + 2 * corrn
+        for name in ("sumI", "sumQ", "oldsumI", "oldsumQ", "II", "QQ"):
+            assert np.array_equal(np.ctypeslib.as_array(getattr(lst[i], name))[:ntap],
+                                  np.ctypeslib.as_array(getattr(o, name))[:ntap]), (i, name)
+        # the loops pulled in
+        assert abs(o.carrfreq - (f_if + dop[i])) < 150.0
+    return ochs
+
+
+def test_closed_loop_before_bit_sync(gc, orc, synth, engine):
+    """prm1 every period (ref src/sdrmain.c:272-276): 220 periods from the acquisition hand-over state,
+    BASELINE tap layout (5 taps, int8 IQ, zero IF)."""
+    _run_case(gc, orc, synth, engine, 2, 0.0, 2, 3, 3, nper=220, flagsync=0, chunks=(1, 100, 119))
+
+
+def test_closed_loop_after_bit_sync(gc, orc, synth, engine):
+    """prm2 whenever checkbit() raises swloop (every 10 periods counted from each channel's own bit edge,
+    ref src/sdrnav.c:241-262): 240 periods, the shipped 13-tap layout on the real 4.092 MHz IF."""
+    _run_case(gc, orc, synth, engine, 1, 4.092e6, 6, 3, 6, nper=240, flagsync=1, chunks=(37, 203))
+
+
+def test_closed_loop_stops_where_data_ends(gc, orc, synth, engine):
+    """sdrtracking() does nothing until bufflocnow > buffloc (ref src/sdrtrk.c:26-30): a run that asks for more
+    periods than the ring holds stops there, per channel, and resumes after more samples arrive."""
+    prns = [7, 19]
+    sig = _signal(gc, synth, prns, [900.0, -2100.0], [100.0, 600.0], 40)
+    nsamples = sig.shape[0]
+    engine.ring_create(1, 2, nsamples)
+    half = 16368 * 20
+    engine.ring_push_raw(1, sig[:half], half)
+    chans = [gc.Channel(p, dtype=2, f_if=0.0) for p in prns]
+    engine.set_channels(chans)
+    engine.trk_set_state([dict(carrfreq=800.0, codefreq=c.crate, remcode=0.0, remcarr=0.0, buffloc=5000 * (i + 1))
+                          for i, c in enumerate(chans)])
+    engine.loop_set([engine.loop_state(i, 800.0) for i in range(2)])
+    engine.trk_run_loop(30)
+    _, _, ns = engine.trk_fetch()
+    log, ndone = engine.trk_fetch_log()
+    # period e of channel i starts at buffloc_e; it runs iff wrpos - nsamp > buffloc_e
+    for i in range(2):
+        b, cnt = 5000 * (i + 1), 0
+        while half - 16368 > b and cnt < 30:
+            b += int(ns[i, cnt])
+            cnt += 1
+        assert ndone[i] == cnt and 15 <= cnt <= 19
+        assert np.all(ns[i, cnt:] == 0)
+    engine.ring_push_raw(1, sig[half:], nsamples - half)
+    engine.trk_run_loop(10)
+    _, ndone2 = engine.trk_fetch_log()
+    assert np.all(ndone2 == 10)

@@ -30,6 +30,7 @@ def nco(tmp_path_factory):
     L.nco_chain_cert.argtypes = [d, d, d, d, d, i, d, i, C.POINTER(i), C.POINTER(d), C.POINTER(d), C.POINTER(i)]
     L.nco_code_period.argtypes = [d, d, i, d, i, i, C.POINTER(d)]
     L.nco_carrier_period.argtypes = [d, d, d, i, C.POINTER(d)]
+    L.nco_period_tables.argtypes = [d, d, d, d, i, d, i, i, vp, vp, C.POINTER(d), C.POINTER(d)]
     L.nco_carrier_fast.argtypes = L.nco_carrier.argtypes
     L.nco_code_fast.argtypes = L.nco_code.argtypes
     return L
@@ -320,3 +321,38 @@ def test_carrier_period_step(nco, orc):
             assert prem.value == oprem, (it, freq, remcarr, prem.value, oprem)
             applied += 1
     assert applied >= 0.9 * total, (applied, total)
+
+
+def test_period_steps_emit_exact_tables(nco, orc):
+    """The period steps with table emission (the closed-loop kernel's planner): every LUT index and every chip
+    read back from the emitted piece tables equals the literal loops'."""
+    rng = np.random.default_rng(55)
+    ti = 1 / F_SF
+    L = orc.lib()
+    cost, sint = _lut()
+    code = np.arange(1023, dtype=np.int16)
+    seen = {1: 0, 2: 0}
+    for it in range(600):
+        freq = [0.0, 4.092e6][it % 2] + float(rng.uniform(-6000, 6000))
+        remcarr = float(rng.uniform(0, DPI)) if freq > 0 else -float(rng.uniform(0, 3e4))
+        codefreq = 1.023e6 + float(rng.uniform(-5, 5))
+        ci = ti * codefreq
+        remcode = float(rng.uniform(0, ci))
+        smax = int(rng.choice([3, 6, 18]))
+        n = int((1023 - remcode) / (codefreq / F_SF))
+        data = np.ones(n, np.int8)
+        I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        rc = np.zeros(n + 2 * smax, np.int16)
+        oprem = L.orc_mixcarr_seq(data.ctypes.data, 1, ti, n, freq, remcarr, I.ctypes.data, Q.ctypes.data)
+        orem = L.orc_rescode_seq(code.ctypes.data, 1023, remcode, smax, ci, n, rc.ctypes.data)
+        idx, chip = np.zeros(n, np.int32), np.zeros(n + 2 * smax, np.int32)
+        prem, rem = C.c_double(), C.c_double()
+        r = nco.nco_period_tables(ti, freq, remcarr, codefreq, 1023, remcode, smax, n, idx.ctypes.data, chip.ctypes.data,
+                                  C.byref(prem), C.byref(rem))
+        if r & 1:
+            assert prem.value == oprem and np.array_equal(cost[idx & 31], I) and np.array_equal(sint[idx & 31], Q), (it, freq, remcarr)
+            seen[1] += 1
+        if r & 2:
+            assert rem.value == orem and np.array_equal(chip, rc), (it, codefreq, remcode, smax)
+            seen[2] += 1
+    assert seen[1] > 500 and seen[2] > 590, seen
