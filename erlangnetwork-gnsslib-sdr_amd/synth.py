@@ -57,7 +57,7 @@ def default_sats(prns, seed=SEED, npresent=10):
     sats = []
     for p in present:
         sats.append(dict(prn=int(p), doppler=float(rng.uniform(-5000, 5000)),
-                         codephase=float(rng.uniform(0, 1023)), cn0=float(rng.uniform(42, 50)),
+                         codephase=float(rng.uniform(0, 1023)), cn0=float(rng.uniform(38, 50)),
                          phase=float(rng.uniform(0, 2 * np.pi)),
                          bits=rng.choice([-1.0, 1.0], size=64)))
     return sats
