@@ -258,6 +258,7 @@ def main():
         for _ in range(args.inner):
             eng.trk_run(E)
 
+    log("tracking leg: warm-up")
     for i in range(args.warmup):
         step(i)
     if pending[0] is not None:
@@ -266,6 +267,7 @@ def main():
     barrier()
     eng.timing(not os.environ.get("BENCH_NOTIMING"))      # (debug) per-kernel HIP events off
     eng.timing_reset()
+    log(f"tracking leg: {args.steps} steps x {args.inner} launches x {E} periods")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -314,11 +316,12 @@ def main():
     }
 
     # ---- closed loop (pll/dll on the device), same channels ----------------
-    if world == 1:
+    if world == 1 and args.loop_periods > 0:
         NP = args.loop_periods
         cl = {"periods": NP, "channels": NCH, "note": "gnsscorr_trk_run_loop: plan, correlate, cumsumcorr, pll/dll per "
               "period on the device, one workgroup per channel; no host round trip inside a run"}
         for name, flagsync in (("loop1_before_bit_sync", 0), ("loop10_after_bit_sync", 1)):
+            log(f"closed loop leg: {name}, {NP} periods")
             eng.trk_set_state([dict(s, buffloc=s["buffloc"] % NSAMP) for s in states0])
             eng.loop_set([eng.loop_state(i, 200.0 * round(states0[i]["carrfreq"] / 200.0), flagsync=flagsync,
                                          synci=(7 * i) % 20, cnt=2001) for i in range(NCH)])
@@ -338,6 +341,7 @@ def main():
 
     # ---- acquisition leg (configs[1]) --------------------------------------
     if not args.no_acq:
+        log("acquisition leg")
         wrpos = acq_hist + NSAMP // 3 + 100 * NSAMP if E > 120 else acq_hist + NSAMP // 3
         for _ in range(2):
             eng.acq_run(wrpos)
@@ -389,6 +393,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
+        log("CPU baseline leg")
         import oracle as orc
         flat = host
         out["cpu_baseline"] = cpu_baseline_tracking(orc, flat, ringlen, chans, states0)

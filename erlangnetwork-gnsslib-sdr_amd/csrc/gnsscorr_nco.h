@@ -31,9 +31,11 @@
 #if defined(__HIPCC__)
 #define GC_HD __host__ __device__ inline
 #define GC_HDM __host__ __device__
+#define GC_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define GC_HD static inline
 #define GC_HDM
+#define GC_HD_NOINLINE static
 #endif
 // no fused multiply-add may be formed from the separate operations written below
 // (gcc: compile with -ffp-contract=off)
@@ -48,6 +50,11 @@
 #define GC_DDIV(a, b) __ddiv_rn((a), (b))
 #else
 #define GC_DDIV(a, b) ((a) / (b))
+#endif
+
+// debug builds (-DGC_LOOP_DEBUG, tools/debug) drop progress marks into host-visible memory
+#ifndef GC_DBG_MARK
+#define GC_DBG_MARK(slot, value) do { } while (0)
 #endif
 
 #define GC_NCO_DPI   (2.0*3.1415926535897932)     // DPI with the reference's PI literal (ref src/sdr.h:103-104)
@@ -898,6 +905,7 @@ struct GcCodePlan {
     double limtop;          // largest value below dlen on its binade's grid
     double smaxci;          // smax*ci (ref :613)
     int    itop;            // table binade that holds limtop
+    int    it;              // the table binade (<= itop) in which ci is a tie, or -1
     bool   exact;           // ci is a multiple of ulp(dlen): no addition of the climb rounds
     bool   ok;              // the table covers the code (else: general walkers only)
 };
@@ -913,6 +921,10 @@ GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax, bool w
     P.ok = P.f.ex0 != 0x7FFFFFF && ci > 0.0 && P.itop >= 1 && P.itop < GC_NB &&
            P.dlen + ci < gc_u2d((uint64_t)(P.f.ex0 + P.itop + 1) << 52) && !((P.f.tie >> P.itop) & 1);
     P.exact = P.ok && gc_cert_exact(P.limtop, ci, P.dlen);
+    P.it = -1;
+#pragma unroll
+    for (int i = 0; i < GC_NB; i++)
+        if (((P.f.tie >> i) & 1) && i <= P.itop) P.it = i;
     if (P.ok && !with_inv) {
 #pragma unroll
         for (int i = 0; i < GC_NB; i++)
@@ -923,24 +935,95 @@ GC_HD void gc_code_plan_init(GcCodePlan &P, double ci, int len, int smax, bool w
 // fill(K, ctx, i0, itop, lim): K[i] = certified crossing of boundary i (i0 < i <= itop: bottom of table
 // binade i; i == GC_NB: lim) relative to ctx.a0 -- gc_cert_lane per boundary; returns false on any
 // GC_CERT_FAIL.  (host: GcFillLoop below; device: one lane per boundary + readlane)
+// The crossings handed back are strictly increasing over i0 < i <= itop, and K[GC_NB] above K[itop] (a
+// fill that finds them otherwise returns false).
 struct GcFillLoop {
     GC_HDM bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
     {
+        int prev = 0;
         for (int i = i0 + 1; i <= GC_NB; i++) {
             K[i] = (i <= itop || i == GC_NB) ? gc_cert_lane(c, i, lim) : GC_CERT_FAR;
             if (K[i] == GC_CERT_FAIL) return false;
+            if (i <= itop || i == GC_NB) {
+                if (K[i] <= prev && !(K[i] == GC_CERT_FAR && (i != GC_NB || !(lim < 1.0e300)))) return false;    // (several may be out of reach)
+                prev = K[i];
+            }
         }
         return true;
     }
 };
 
-// emit(j0, y0, d, count, w) receives the pieces (as gc_code_walk's emitter does) when the step applies;
-// on a false return the emitter may have seen some pieces already: reset it before the fallback.
-template <class Fill, class Emit>
-GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+// The climb's chain for a table whose binade ITOP holds the code length: written for a compile-time ITOP
+// so that nothing but one fma and one addition per binade sits on the dependency path (the loop bounds,
+// the table entries and the tie test are constants or scalar work beside it).
+template <int ITOP, class Emit>
+GC_HD bool gc_code_climb(const GcNcoFast &f, const int *K, int i0, int cn, double ci, double *py, int *pk, int jbase, Emit &emit)
 {
     GC_FP_STRICT
-    if (!P.ok) return false;
+    double y = *py;
+    int k = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i <= ITOP; i++) {
+        const bool active = i >= i0;                // (i0 is 0 or 1)
+        const int Kn = i == ITOP ? K[GC_NB] : K[i + 1];
+        int last = Kn - 1;
+        last = last > cn - 1 ? cn - 1 : last;
+        int m = last - k;
+        ok = ok && (m >= 0 || !active);
+        int kb = k;
+        if ((f.tie >> i) & 1) {                     // (at most one table binade: a scalar branch)
+            const bool odd = active && (gc_d2u(y) & 1) && m > 0;
+            if (odd) emit(jbase + kb, y, 0.0, 1, 1);
+            const double yl = y + ci;
+            y = odd ? yl : y;
+            m -= odd ? 1 : 0;
+            kb += odd ? 1 : 0;
+        }
+        m = active ? m : 0;
+        if (active && m >= 0) emit(jbase + kb, y, f.d[i], m + 1, 1);
+        const double yn = fma((double)m, f.d[i], y) + ci;
+        y = active ? yn : y;
+        k = active ? last + 1 : k;
+    }
+    *py = y;
+    *pk = k;
+    return ok;
+}
+
+// The same with the second wrap inside the period (always, for a tracked channel) and the crossings known
+// to increase: no test is left beside the two operations, except in the one binade (if any: `it`, else -1)
+// in which the addend is a tie -- entered on an odd multiplier, its first step is the reference's own
+// addition (it rounds to the even neighbour), the rest are the table's.
+template <int ITOP, class Emit>
+GC_HD void gc_code_climb_lean(const GcNcoFast &f, const int *K, int i0, int it, double ci, double *py, int jbase, Emit &emit)
+{
+    GC_FP_STRICT
+    double y = *py;
+#pragma unroll
+    for (int i = 0; i <= ITOP; i++) {
+        if (i == 0 && i0 != 0) continue;
+        int ks = (i == i0) ? 0 : K[i];
+        const int ke = i == ITOP ? K[GC_NB] : K[i + 1];
+        if (i == it) {
+            if ((gc_d2u(y) & 1) && ke - 1 - ks > 0) {
+                emit(jbase + ks, y, 0.0, 1, 1);
+                y = y + ci;
+                ks += 1;
+            }
+        }
+        emit(jbase + ks, y, f.d[i], ke - ks, 1);
+        y = fma((double)(ke - 1 - ks), f.d[i], y) + ci;
+    }
+    *py = y;
+}
+
+// emit(j0, y0, d, count, w) receives the pieces (as gc_code_walk's emitter does) when the step applies;
+// on a false return the emitter may have seen some pieces already: reset it before the fallback.
+template <int ITOP, class Fill, class Emit>
+GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+{
+    GC_FP_STRICT
     const GcNcoFast &f = P.f;
     const double ci = f.s, dlen = P.dlen;
     // ---- start value (ref :613-614) and head: c0 + j d_top < len for j <= q
@@ -948,13 +1031,13 @@ GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fil
     const double fl = cs < 0.0 ? -1.0 : 0.0;
     if (!(cs >= -dlen && cs < dlen)) return false;
     const double c0 = cs - fl * dlen;
-    if ((int)((gc_d2u(c0) >> 52) & 0x7FF) != f.ex0 + P.itop || !(c0 < dlen)) return false;
-    const double dtop = f.d[P.itop < GC_NB ? P.itop : 0];
+    if ((int)((gc_d2u(c0) >> 52) & 0x7FF) != f.ex0 + ITOP || !(c0 < dlen)) return false;
+    const double dtop = f.d[ITOP];
     double y;
     int j;
     {
         const double R = P.limtop - c0;
-        double q = floor(R * f.inv[P.itop < GC_NB ? P.itop : 0]);
+        double q = floor(R * f.inv[ITOP]);
         const double r = fma(-q, dtop, R);
         q += r < 0.0 ? -1.0 : (r >= dtop ? 1.0 : 0.0);
         if (!(q >= 0.0 && q < (double)(nt - 2))) return false;
@@ -984,41 +1067,45 @@ GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fil
     const int i0 = (int)((gc_d2u(y) >> 52) & 0x7FF) - f.ex0;
     if (i0 < 0 || i0 > 1) return false;
     int K[GC_NB + 1];
-    if (!fill(K, c, i0, P.itop, dlen)) return false;
-    int k = 0;
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < GC_NB; i++) {
-        if (i < i0 || i > P.itop) continue;
-        const int Kn = i == P.itop ? K[GC_NB] : K[i + 1];
-        int last = Kn - 1;
-        last = last > c.n - 1 ? c.n - 1 : last;
-        int m = last - k;
-        ok = ok && m >= 0;
-        int kb = k;
-        if ((f.tie >> i) & 1) {                     // (at most one table binade: a uniform branch)
-            const bool odd = (gc_d2u(y) & 1) && m > 0;
-            if (odd) emit(j + kb, y, 0.0, 1, 1);
-            const double yl = y + ci;
-            y = odd ? yl : y;
-            m -= odd ? 1 : 0;
-            kb += odd ? 1 : 0;
-        }
-        if (m >= 0) emit(j + kb, y, f.d[i], m + 1, 1);
-        y = fma((double)m, f.d[i], y);
-        y = y + ci;
-        k = last + 1;
-    }
-    j += k;
-    if (!ok || j >= nt || !(y >= dlen)) return false;       // (the period must end in the tail)
+    if (!fill(K, c, i0, ITOP, dlen)) return false;
+    if (K[GC_NB] >= c.n) return false;              // (the period must end in the tail)
+    gc_code_climb_lean<ITOP>(f, K, i0, P.it, ci, &y, j, emit);
+    j += K[GC_NB];
+    if (j >= nt || !(y >= dlen)) return false;
     // ---- second wrap and tail
     y = y - dlen;
-    for (int t = nt - j; t > 0; t--) {
+    int t = nt - j;
+    for (; t >= 4; t -= 4) {                        // (the reference's own additions, four per trip)
+        emit(nt - t, y, 0.0, 1, 2);
+        y = y + ci;
+        emit(nt - t + 1, y, 0.0, 1, 2);
+        y = y + ci;
+        emit(nt - t + 2, y, 0.0, 1, 2);
+        y = y + ci;
+        emit(nt - t + 3, y, 0.0, 1, 2);
+        y = y + ci;
+    }
+    for (; t > 0; t--) {
         emit(nt - t, y, 0.0, 1, 2);
         y = y + ci;
     }
     *remcode_out = y - P.smaxci;
     return true;
+}
+
+template <class Fill, class Emit>
+GC_HD bool gc_code_period(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+{
+    if (!P.ok) return false;
+    switch (P.itop) {           // (GPS / GLONASS codes at 2..64 samples per chip: 7..12)
+    case 7:  return gc_code_period_t<7>(P, remcode, nt, fill, remcode_out, emit);
+    case 8:  return gc_code_period_t<8>(P, remcode, nt, fill, remcode_out, emit);
+    case 9:  return gc_code_period_t<9>(P, remcode, nt, fill, remcode_out, emit);
+    case 10: return gc_code_period_t<10>(P, remcode, nt, fill, remcode_out, emit);
+    case 11: return gc_code_period_t<11>(P, remcode, nt, fill, remcode_out, emit);
+    case 12: return gc_code_period_t<12>(P, remcode, nt, fill, remcode_out, emit);
+    default: return false;
+    }
 }
 
 template <class Fill>
@@ -1129,8 +1216,13 @@ struct GcFillLanes {
     __device__ bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
     {
         int Kl = GC_CERT_FAR;
-        if (lane > i0 && lane <= GC_NB && (lane <= itop || lane == GC_NB)) Kl = gc_cert_lane(c, lane, lim);
-        if (__any(Kl == GC_CERT_FAIL)) return false;
+        const bool mine = lane > i0 && lane <= GC_NB && (lane <= itop || lane == GC_NB);
+        if (mine) Kl = gc_cert_lane(c, lane, lim);
+        // strictly increasing: against the lane below (lane GC_NB against lane itop)
+        const int src = lane == GC_NB ? itop : lane - 1;
+        const int below = __shfl(Kl, src < 0 ? 0 : src, 64);
+        const bool bad = mine && (Kl == GC_CERT_FAIL || (src > i0 && Kl <= below && !(Kl == GC_CERT_FAR && (lane != GC_NB || !(lim < 1.0e300)))) || Kl <= 0);
+        if (__any(bad)) return false;
 #pragma unroll
         for (int i = 0; i <= GC_NB; i++) K[i] = __builtin_amdgcn_readlane(Kl, i);
         return true;

@@ -21,6 +21,24 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifdef GC_LOOP_DEBUG
+// progress marks of the closed-loop kernel in host-visible memory (tools/debug/loop_marks.py)
+#include <hip/hip_runtime.h>
+__device__ unsigned long long *gc_dbg_marks = nullptr;
+#define GC_DBG_MARK(slot, value) do { if (gc_dbg_marks && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { \
+        __hip_atomic_store(&gc_dbg_marks[slot], (unsigned long long)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
+extern "C" int gnsscorr_debug_marks(void **host)
+{
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 4096, hipHostMallocMapped) != hipSuccess) return -1;
+    for (int i = 0; i < 512; i++) ((unsigned long long *)h)[i] = 0;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gc_dbg_marks), &d, sizeof(d)) != hipSuccess) return -1;
+    *host = h;
+    return 0;
+}
+#endif
+
 #include "gnsscorr_internal.h"
 
 namespace {
@@ -69,11 +87,11 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
     const bool do_code = wave == 0, do_car = wave == 1 || !split;
     // per-binade constants of the addends (the frequencies are held over the batch) and the
     // shape-specialised period steps built on them
-    GcNcoFast fcar, fcode, fprem;
     GcCodePlan PC;
     GcCarPlan PK;
-    if (do_code) { gc_fast_init(fcode, ci); gc_code_plan_init(PC, ci, c.clen, c.smax); }
-    if (do_car) { gc_fast_init(fcar, ps); gc_fast_init(fprem, -GC_NCO_DPI); gc_car_plan_init(PK, ps); }
+    if (do_code) gc_code_plan_init(PC, ci, c.clen, c.smax);
+    if (do_car) gc_car_plan_init(PK, ps);
+    const GcNcoFast &fcode = PC.f, &fcar = PK.f, &fprem = PK.fprem;
     const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
     const double smaxci = __dmul_rn((double)c.smax, ci);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
@@ -796,7 +814,10 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // inside them (the common case -- a piece is a whole binade of the running phase) every lane
         // steps the same piece, otherwise each lane finds its own and switches where the next one starts
         const int kw = kl + wv * 64 * LSP;
+        GC_DBG_MARK(6, 1000 * r + wseg);
+        GC_DBG_MARK(7, sk0[wseg + 1]);
         while (sk0[wseg + 1] <= kw) wseg++;
+        GC_DBG_MARK(6, 1000 * r + wseg + 500);
         const bool onepiece = sk0[wseg + 1] >= kw + 64 * LSP;
         auto run = [&](auto multi_tag) {
             constexpr bool MULTI = decltype(multi_tag)::value;
@@ -1091,7 +1112,7 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                                                        double *__restrict__ corrI, double *__restrict__ corrQ,
                                                        int *__restrict__ nsamp_out, gnsscorr_trklog_t *__restrict__ log,
                                                        int *__restrict__ ndone, int *__restrict__ nco_overflow, int nch,
-                                                       int nper, int nseg, int max_n, int rpw)
+                                                       int nper, int nseg, int max_n, int rpw, int ablate)
 {
     using L = PsLayout<DTYPE, NIT>;
     __shared__ __attribute__((aligned(16))) char smem[L::bytes(NTAP)];
@@ -1117,10 +1138,13 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
     GcCodeSeg *scode = reinterpret_cast<GcCodeSeg *>(smem + L::CODE_OFF);
     const uint64_t wp = wrpos[ch];
 
-    // wavefront 0 keeps the chained state in registers
+    // wavefront 0 keeps the chained state in registers; the step tables of the two NCOs live in LDS (in
+    // registers they would push the correlator's accumulators out)
     GcTrkState st = state[ch];
-    GcCodePlan PC;
-    GcCarPlan PK;
+    __shared__ GcCodePlan sPC;
+    __shared__ GcCarPlan sPK;
+    GcCodePlan &PC = sPC;
+    GcCarPlan &PK = sPK;
     GcFillLanes fill{lane};
     double lastcarr = 0.0, lastcode = 0.0;
     bool have_plan = false;
@@ -1154,6 +1178,7 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                 u.ncar = u.ncode = 0;
                 double remcarr = st.remcarr, remcode = st.remcode;
                 const bool valid = n > 0 && n <= max_n && ci > 0.0 && ci < dlen;
+                GC_DBG_MARK(0, 100 * p + 1);
                 if (valid) {
                     LdsCarTable ct{sk0, scar, 0, 0};
                     GcCodeTable dt{scode, GC_NCODE, 0, 0};
@@ -1167,15 +1192,19 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                         const double xn = gc_fast_carrier_walk(PK.f, gc_carrier_phis(st.remcarr), n, ct);
                         remcarr = gc_fast_prem(PK.fprem, xn);
                     }
+                    GC_DBG_MARK(0, 100 * p + 2);
                     if (gc_code_period(PC, st.remcode, nt, fill, &r, dt)) {
                         remcode = r;
                     } else {
+                        GC_DBG_MARK(0, 100 * p + 3);
                         dt.n = 0;
                         dt.overflow = 0;
                         gc_fast_init(PC.f, ci);
+                        GC_DBG_MARK(0, 100 * p + 4);
                         const double cend = gc_fast_code_walk(PC.f, gc_code_start(st.remcode, c.smax, ci, c.clen), c.clen, nt, dt);
                         remcode = gc_code_rem(cend, c.smax, ci);
                     }
+                    GC_DBG_MARK(0, 100 * p + 5);
                     u.ncar = ct.n;
                     u.ncode = dt.n;
                     if (ct.overflow || dt.overflow) {
@@ -1224,11 +1253,13 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
         }
         __syncthreads();
         if (!sgo) break;
+        GC_DBG_MARK(0, 100 * p + 6);
         // ---- correlate: the whole workgroup, one share of the period after the other
         for (int sg = 0; sg < nseg && sg < GC_LOOP_MAXSEG; sg++) {
-            ps_unit<DTYPE, NTAP, NIT>(c, su, (const GcUnitSegs *)nullptr, sr[sg], spart[sg], NTAP, max_n, rpw, sg, 0, smem, tid);
+            ps_unit<DTYPE, NTAP, NIT>(c, su, (const GcUnitSegs *)nullptr, sr[sg], spart[sg], NTAP, max_n, rpw, sg, ablate, smem, tid);
             __syncthreads();
         }
+        GC_DBG_MARK(0, 100 * p + 7);
         // ---- outputs, cumsumcorr, loop filters (ref src/sdrtrk.c:35-36,42,64-86; src/sdrmain.c:269-310)
         if (wave == 0) {
             if (lane < ntap) {
@@ -1257,6 +1288,7 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
             }
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
+            GC_DBG_MARK(0, 100 * p + 8);
             // loop timing of sdrnavigation()/checkbit() (ref src/sdrnav.c:18,241-262)
             int flag = 0;
             const int flagsync = lp->flagsync;
@@ -1294,6 +1326,7 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                 lp->swloop = swloop;
                 lp->cnt = cnt + 1;
             }
+            GC_DBG_MARK(0, 100 * p + 9);
             // the new frequencies, for every lane of the planning wavefront
             flag = __builtin_amdgcn_readfirstlane(flag);
             st.carrfreq = gc_u2d(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gc_d2u(st.carrfreq) >> 32)) << 32) |
@@ -1310,11 +1343,13 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
             __builtin_amdgcn_wave_barrier();
         }
     }
+    GC_DBG_MARK(10, 1 + (threadIdx.x >> 6));
     if (tid == 0) {
         state[ch] = st;
         ndone[ch] = p;
     }
     __syncthreads();
+    GC_DBG_MARK(11, 1 + (threadIdx.x >> 6));
     {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(loop + ch);
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&slp);
@@ -1461,8 +1496,9 @@ int launch_loop_taps(hipStream_t st, const GcChan *chan, GcTrkState *state, gnss
 {
     constexpr int NIT = DTYPE == 1 ? 1 : 2;
     const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
+    static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
 #define GC_LL(N) do { hipLaunchKernelGGL((trk_loop_kernel<DTYPE, N, NIT>), dim3(nch), dim3(256), 0, st, chan, state, loop, wrpos, \
-                                         corrI, corrQ, nsamp_out, log, ndone, nco_overflow, nch, nper, nseg, max_n, rpw); \
+                                         corrI, corrQ, nsamp_out, log, ndone, nco_overflow, nch, nper, nseg, max_n, rpw, ablate); \
                       GC_HIP(hipGetLastError()); return 0; } while (0)
     if (ntap <= 3) GC_LL(3);
     if (ntap <= 5) GC_LL(5);

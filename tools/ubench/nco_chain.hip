@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "gnsscorr_nco.h"
+#include "code_period_prof.h"
 
 struct Cnt { int n = 0; __host__ __device__ void operator()(int, double, double, int) { n++; } __host__ __device__ void operator()(int, double, double, int, int) { n++; } };
 
@@ -21,6 +22,7 @@ __global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double ca
     const double yspc = 1.0 / spc, ydpi = 1.0 / GC_NCO_DPI, smaxci = smax * ci;
     double remcode = 0, remcarr = 0;
     Cnt c1, c2;
+    long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     GcCodePlan PC;
     GcCarPlan PK;
     gc_code_plan_init(PC, ci, len, smax);
@@ -48,18 +50,20 @@ __global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double ca
         }
         if (mode & 64) { double rp; if (gc_carrier_period(PK, remcarr, n, fill, &rp)) remcarr = rp; else { GcNoEmit ne; c1.n++; remcarr = gc_fast_prem(fprem, gc_fast_carrier_walk(fcar, gc_div_y(remcarr * 32.0, GC_NCO_DPI, ydpi), n, ne)); } }
         if (mode & 128) { double rc; if (gc_code_period(PC, remcode, n + 2 * smax, fill, &rc)) remcode = rc; else { GcNoEmit ne; c2.n++; remcode = gc_fast_code_walk(fcode, gc_code_start_fast(remcode, smaxci, len), len, n + 2 * smax, ne) - smaxci; } }
+        if (mode & 256) { double rc; GcNoEmit ne; if (gc_code_period_prof<11>(T, PC, remcode, n + 2 * smax, fill, &rc, ne)) remcode = rc; else c2.n++; }
         if (mode & 8) remcode = gc_code_rem(gc_code_walk(gc_code_start(remcode, smax, ci, len), ci, len, n + 2 * smax, c2), smax, ci);
     }
     const long long t1 = wall_clock64();
+    if (lane == 0 && (mode & 256)) for (int i = 0; i < 5; i++) out[4 + i] = (double)T[i] / nper;
     if (lane == 0) { out[0] = remcode; out[1] = remcarr; out[2] = c1.n; out[3] = c2.n; clk[0] = t1 - t0; }
 }
 
 int main()
 {
     double *out; long long *clk;
-    hipMalloc(&out, 64); hipMalloc(&clk, 8);
+    hipMalloc(&out, 128); hipMalloc(&clk, 8);
     const int nper = 2000;
-    for (int mode : {2, 64, 128, 192}) for (double cf : {2345.6, -2345.6, 4.0932e6}) {
+    for (int mode : {128, 256}) for (double cf : {2345.6, -2345.6, 4.0932e6}) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, mode, 10, cf, 1.023e6 + 1.3, out, clk);
         hipEventRecord(a);
@@ -67,7 +71,8 @@ int main()
         hipEventRecord(b);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, a, b);
-        double h[4]; long long c; hipMemcpy(h, out, 32, hipMemcpyDeviceToHost); hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+        double h[10]; long long c; hipMemcpy(h, out, 80, hipMemcpyDeviceToHost); hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+        if (mode & 256) printf("  shader clocks/period: head %.0f literal %.0f fill %.0f chain %.0f tail %.0f\n", h[4], h[5], h[6], h[7], h[8]);
         printf("mode %d carr %.1f: %.3f us/period (%.0f wall-clock ticks/period), pieces/period car %.1f code %.1f, rem %.6g %.6g\n", mode, cf,
                ms * 1e3 / nper, (double)c / nper, h[2] / nper, h[3] / nper, h[0], h[1]);
     }
