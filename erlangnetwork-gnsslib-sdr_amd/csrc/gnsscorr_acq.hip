@@ -26,6 +26,7 @@
 //   acq_final (per channel): the decision of checkacquisition() after each
 //            iteration, first success wins (ref src/sdracq.c:39-42).
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gnsscorr_ctx.h"
@@ -55,6 +56,9 @@ struct GcAcqWork {
     float2 *tw16k = nullptr;    // exp(-2 pi i t/16384), t < 16384
     float2 *tw32k = nullptr;    // exp(-2 pi i t/32768), t < 16384
     float2 *tw32p = nullptr;    // the same twiddles in pass order: exp(-2 pi i freq_of(p)/32768), p < 16384
+    float2 *tw64p1 = nullptr;   // exp(-2 pi i freq_of(p)/65536) and
+    float2 *tw64p3 = nullptr;   // exp(-2 pi i 3 freq_of(p)/65536), pass order (the 65536-point path)
+    int L = GC_L;               // transform length of this channel set: 32768, or 65536 when a period exceeds 16384 samples
     float2 *X = nullptr;        // [grid][iter][bin][2][16384]: X[f] and X[f + 16384] at the pass position of f
     size_t  X_elems = 0;
     float2 *C = nullptr;        // [ch][2][16384]
@@ -79,6 +83,17 @@ __constant__ signed char aCos32[32] = {32, 31, 30, 27, 23, 18, 12, 6, 0, -6, -12
                                        -32, -31, -30, -27, -23, -18, -12, -6, 0, 6, 12, 18, 23, 27, 30, 31};
 __constant__ signed char aSin32[32] = {0, 6, 12, 18, 23, 27, 30, 31, 32, 31, 30, 27, 23, 18, 12, 6,
                                        0, -6, -12, -18, -23, -27, -30, -31, -32, -31, -30, -27, -23, -18, -12, -6};
+
+__global__ void tw64_init_kernel(float2 *tw64p1, float2 *tw64p3)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= GC_LH) return;
+    double s, c;
+    sincospi(-2.0 * (double)gcfft::freq_of(t) / 65536.0, &s, &c);
+    tw64p1[t] = make_float2((float)c, (float)s);
+    sincospi(-2.0 * 3.0 * (double)gcfft::freq_of(t) / 65536.0, &s, &c);
+    tw64p3[t] = make_float2((float)c, (float)s);
+}
 
 __global__ void tw_init_kernel(float2 *tw16k, float2 *tw32k, float2 *tw32p)
 {
@@ -128,6 +143,82 @@ __device__ __forceinline__ void fwd32k_store(F sample, float2 *lds, const float2
                    lds, tw16k, tid);
 }
 
+// Forward 65536-point transform (code periods of 16385..32768 samples: 20 / 26 Msps front ends, ref
+// frontend/stereo_L1G1.ini), decimated in time by four: E_r = FFT16k(x[4j + r]),
+//     X[f + 16384 q] = sum_r (-i)^(r q) w^(r f) E_r[f],   w = exp(-2 pi i/65536), f < 16384,
+// stored as out[q][p] (p = pass position of f): the four values the inverse transform wants side by side.
+// With a_r = w^(r f) E_r:  P+- = E_0 +- a_2, Q+- = a_1 +- a_3,
+//     X_0 = P+ + Q+,  X_2 = P+ - Q+,  X_1 = P- - i Q-,  X_3 = P- + i Q-.
+// The partial results wait in `out` between the four sub-transforms (each lane reads back what it wrote).
+template <class F>
+__device__ __forceinline__ void fwd64k_store(F sample, float2 *lds, const float2 *__restrict__ tw16k,
+                                             const float2 *__restrict__ tw32p, const float2 *__restrict__ tw64p1,
+                                             const float2 *__restrict__ tw64p3, float2 *__restrict__ out, int tid)
+{
+    auto put = [](float2 *dst, float2 x0, float2 x1, float2 x2, float2 x3) {
+        float4 *d = reinterpret_cast<float4 *>(dst);
+        d[0] = make_float4(x0.x, x0.y, x1.x, x1.y);
+        d[1] = make_float4(x2.x, x2.y, x3.x, x3.y);
+    };
+    auto get = [](const float2 *src, float2 (&v)[4]) {
+        const float4 *d = reinterpret_cast<const float4 *>(src);
+        const float4 a = d[0], b = d[1];
+        v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w);
+        v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
+    };
+    // r = 0: E_0 -> out[0]
+    gcfft::dif<-1>([&](int j) { return sample(4 * j); },
+                   [&](int p, float2 x0, float2 x1, float2 x2, float2 x3) { put(out + p, x0, x1, x2, x3); },
+                   lds, tw16k, tid);
+    __syncthreads();
+    // r = 2: P+ -> out[0], P- -> out[1]
+    gcfft::dif<-1>([&](int j) { return sample(4 * j + 2); },
+                   [&](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                       float2 e[4], t[4];
+                       get(out + p, e);
+                       get(tw32p + p, t);
+                       const float2 a[4] = {cmul(x0, t[0]), cmul(x1, t[1]), cmul(x2, t[2]), cmul(x3, t[3])};
+                       put(out + p, cadd(e[0], a[0]), cadd(e[1], a[1]), cadd(e[2], a[2]), cadd(e[3], a[3]));
+                       put(out + GC_LH + p, csub(e[0], a[0]), csub(e[1], a[1]), csub(e[2], a[2]), csub(e[3], a[3]));
+                   },
+                   lds, tw16k, tid);
+    __syncthreads();
+    // r = 1: a_1 -> out[2]
+    gcfft::dif<-1>([&](int j) { return sample(4 * j + 1); },
+                   [&](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                       float2 t[4];
+                       get(tw64p1 + p, t);
+                       put(out + 2 * GC_LH + p, cmul(x0, t[0]), cmul(x1, t[1]), cmul(x2, t[2]), cmul(x3, t[3]));
+                   },
+                   lds, tw16k, tid);
+    __syncthreads();
+    // r = 3: the four outputs
+    gcfft::dif<-1>([&](int j) { return sample(4 * j + 3); },
+                   [&](int p, float2 x0, float2 x1, float2 x2, float2 x3) {
+                       float2 t[4], a1[4], pp[4], pm[4];
+                       get(tw64p3 + p, t);
+                       get(out + 2 * GC_LH + p, a1);
+                       get(out + p, pp);
+                       get(out + GC_LH + p, pm);
+                       const float2 a3[4] = {cmul(x0, t[0]), cmul(x1, t[1]), cmul(x2, t[2]), cmul(x3, t[3])};
+                       float2 X0[4], X1[4], X2[4], X3[4];
+#pragma unroll
+                       for (int i = 0; i < 4; i++) {
+                           const float2 qp = cadd(a1[i], a3[i]), qm = csub(a1[i], a3[i]);
+                           const float2 iqm = make_float2(-qm.y, qm.x);            // i Q-
+                           X0[i] = cadd(pp[i], qp);
+                           X2[i] = csub(pp[i], qp);
+                           X1[i] = csub(pm[i], iqm);
+                           X3[i] = cadd(pm[i], iqm);
+                       }
+                       put(out + p, X0[0], X0[1], X0[2], X0[3]);
+                       put(out + GC_LH + p, X1[0], X1[1], X1[2], X1[3]);
+                       put(out + 2 * GC_LH + p, X2[0], X2[1], X2[2], X2[3]);
+                       put(out + 3 * GC_LH + p, X3[0], X3[1], X3[2], X3[3]);
+                   },
+                   lds, tw16k, tid);
+}
+
 // one lane per (grid, bin): the bin's carrier piece table
 __global__ void acq_nco_kernel(const GcChan *__restrict__ chan, const int *__restrict__ grid_chan,
                                const double *__restrict__ freqs, GcAcqCar *__restrict__ car, int ngrid, int maxfreq,
@@ -150,7 +241,8 @@ __global__ void acq_nco_kernel(const GcChan *__restrict__ chan, const int *__res
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
     const GcChan *__restrict__ chan, const int *__restrict__ grid_chan, const GcAcqCar *__restrict__ car,
     const uint64_t *__restrict__ grid_wrpos, const float2 *__restrict__ tw16k,
-    const float2 *__restrict__ tw32p, float2 *__restrict__ X, int maxfreq, int maxintg)
+    const float2 *__restrict__ tw32p, const float2 *__restrict__ tw64p1, const float2 *__restrict__ tw64p3,
+    float2 *__restrict__ X, int maxfreq, int maxintg, int L)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -190,15 +282,18 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_fwd_kernel(
         }
         return make_float2((float)I * sc, (float)Q * sc);
     };
-    float2 *out = X + (((size_t)g * maxintg + it) * maxfreq + bin) * GC_L;
-    fwd32k_store(sample, lds, tw16k, tw32p, out, tid);
+    float2 *out = X + (((size_t)g * maxintg + it) * maxfreq + bin) * (size_t)L;
+    if (L == 2 * GC_L) fwd64k_store(sample, lds, tw16k, tw32p, tw64p1, tw64p3, out, tid);
+    else fwd32k_store(sample, lds, tw16k, tw32p, out, tid);
 }
 
 // acq_code: grid (channel)
 __global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *__restrict__ chan,
                                                                   const float2 *__restrict__ tw16k,
                                                                   const float2 *__restrict__ tw32p,
-                                                                  float2 *__restrict__ C)
+                                                                  const float2 *__restrict__ tw64p1,
+                                                                  const float2 *__restrict__ tw64p3,
+                                                                  float2 *__restrict__ C, int L)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -214,7 +309,8 @@ __global__ __launch_bounds__(GC_FFT_THREADS) void acq_code_kernel(const GcChan *
         while (t >= clen) t -= clen;
         return make_float2((float)code[(int)t], 0.f);
     };
-    fwd32k_store(sample, lds, tw16k, tw32p, C + (size_t)ch * GC_L, tid);
+    if (L == 2 * GC_L) fwd64k_store(sample, lds, tw16k, tw32p, tw64p1, tw64p3, C + (size_t)ch * L, tid);
+    else fwd32k_store(sample, lds, tw16k, tw32p, C + (size_t)ch * L, tid);
 }
 
 // ---- workgroup reductions used by acq_corr --------------------------------
@@ -412,6 +508,178 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     }
 }
 
+// acq_corr for the 65536-point transform: one workgroup of 512 lanes per (bin, channel).  The inverse
+// transform split by lag mod 4 -- with F = f + 16384 q and k = 4 j + s,
+//     y[4j + s] = IFFT_16k( w^(-f s) sum_q i^(q s) Y[f + 16384 q] )[j],   Y = X conj(C), w = exp(-2 pi i/65536)
+// -- so that, as in the 32768-point kernel, every 16384-point transform ends in final lags and the
+// only long-lived registers are the power accumulators: lane `tid` owns lags 4 (tid + 512 h + 1024 q) + s,
+// h < 2, q < 8, s < 4 (lags below nsamp <= 32768), register index 16 s + 8 h + q.
+struct RawXC4 { float4 x[4][2], c[4][2]; };
+
+__global__ __launch_bounds__(512) void acq_corr64_kernel(
+    const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32p,
+    const float2 *__restrict__ tw64p1, const float2 *__restrict__ tw64p3,
+    const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
+    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg, int nchg)
+{
+    constexpr int NT = 512, L = 2 * GC_L, NP = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 32 doubles
+    int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 256);       // 16 ints
+    const int tid0 = threadIdx.x;
+    const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int bin = Pout ? qq * 8 + slot : qq % maxfreq;
+    const int ch = Pout ? pout_ch : (qq / maxfreq) * 8 + slot;
+    if (bin >= maxfreq || (!Pout && ch >= nchg)) return;
+    const GcChan &c = chan[ch];
+    if (bin >= c.nfreq) return;
+    const int n = c.nsamp, nit = iters[ch], nsc2 = 2 * c.nsampchip;
+    const float2 *Cc = C + (size_t)ch * L;
+    const float invL2 = 1.0f / ((float)L * (float)L);
+    double P[NP];
+#pragma unroll
+    for (int s = 0; s < NP; s++) P[s] = 0.0;
+    auto lag_of = [](int tid, int s) { return 4 * (tid + 512 * ((s >> 3) & 1) + 1024 * (s & 7)) + (s >> 4); };
+    for (int it = 0; it < nit; it++) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const float2 *Xb = X + (((size_t)c.grid * maxintg + it) * maxfreq + bin) * (size_t)L;
+        auto load = [Xb, Cc](int p) {
+            RawXC4 r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                r.x[q][0] = *reinterpret_cast<const float4 *>(Xb + q * GC_LH + p);
+                r.x[q][1] = *reinterpret_cast<const float4 *>(Xb + q * GC_LH + p + 2);
+                r.c[q][0] = *reinterpret_cast<const float4 *>(Cc + q * GC_LH + p);
+                r.c[q][1] = *reinterpret_cast<const float4 *>(Cc + q * GC_LH + p + 2);
+            }
+            return r;
+        };
+        // Y_q at position k (0..3) of the butterfly
+        auto Y = [](const RawXC4 &r, int q, int k) {
+            const float4 xv = r.x[q][k >> 1], cv = r.c[q][k >> 1];
+            return (k & 1) ? cmulc(make_float2(xv.z, xv.w), make_float2(cv.z, cv.w))
+                           : cmulc(make_float2(xv.x, xv.y), make_float2(cv.x, cv.y));
+        };
+        auto residue = [&](auto s_tag) {
+            constexpr int S = decltype(s_tag)::value;
+            gcfft::dit<+1, NT, 1>(
+                [&](int p) { return load(p); },
+                [&](const RawXC4 &r, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+                    float2 z[4];
+                    // (the pass position of this butterfly: recomputed from the lane, dit() fetched it at 4*(tid + NT*i))
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float2 y0 = Y(r, 0, k), y1 = Y(r, 1, k), y2 = Y(r, 2, k), y3 = Y(r, 3, k);
+                        float2 v;
+                        if (S == 0) v = cadd(cadd(y0, y2), cadd(y1, y3));
+                        else if (S == 2) v = csub(cadd(y0, y2), cadd(y1, y3));
+                        else {
+                            const float2 d = csub(y1, y3), id = make_float2(-d.y, d.x);      // i (y1 - y3)
+                            v = S == 1 ? cadd(csub(y0, y2), id) : csub(csub(y0, y2), id);
+                        }
+                        z[k] = v;
+                    }
+                    x0 = z[0]; x1 = z[1]; x2 = z[2]; x3 = z[3];
+                },
+                [&](int h, int, float2 (&a)[16]) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const float pw = fmaf(a[q].x, a[q].x, a[q].y * a[q].y) * invL2;
+                        P[16 * S + 8 * h + q] += (double)pw;
+                    }
+                },
+                lds, tw16k, tid);
+        };
+        (void)residue;
+        // The twiddle w^(-f s) has to be applied per input: dit() hands `make` only the raw operands, so the
+        // twiddled variants fetch their factors with the operands.
+        struct RawT { RawXC4 r; float4 ta, tb; };
+        auto residue_tw = [&](auto s_tag, const float2 *__restrict__ twp) {
+            constexpr int S = decltype(s_tag)::value;
+            gcfft::dit<+1, NT, 1>(
+                [&](int p) {
+                    RawT t;
+                    t.r = load(p);
+                    t.ta = *reinterpret_cast<const float4 *>(twp + p);
+                    t.tb = *reinterpret_cast<const float4 *>(twp + p + 2);
+                    return t;
+                },
+                [&](const RawT &t, float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+                    float2 z[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float2 y0 = Y(t.r, 0, k), y1 = Y(t.r, 1, k), y2 = Y(t.r, 2, k), y3 = Y(t.r, 3, k);
+                        float2 v;
+                        if (S == 2) v = csub(cadd(y0, y2), cadd(y1, y3));
+                        else {
+                            const float2 d = csub(y1, y3), id = make_float2(-d.y, d.x);
+                            v = S == 1 ? cadd(csub(y0, y2), id) : csub(csub(y0, y2), id);
+                        }
+                        const float2 w = k == 0 ? make_float2(t.ta.x, t.ta.y) : k == 1 ? make_float2(t.ta.z, t.ta.w)
+                                       : k == 2 ? make_float2(t.tb.x, t.tb.y) : make_float2(t.tb.z, t.tb.w);
+                        z[k] = cmulc(v, w);          // exp(+2 pi i f s/65536) = conj of the forward twiddle
+                    }
+                    x0 = z[0]; x1 = z[1]; x2 = z[2]; x3 = z[3];
+                },
+                [&](int h, int, float2 (&a)[16]) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const float pw = fmaf(a[q].x, a[q].x, a[q].y * a[q].y) * invL2;
+                        P[16 * S + 8 * h + q] += (double)pw;
+                    }
+                },
+                lds, tw16k, tid);
+        };
+        residue(std::integral_constant<int, 0>{});
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        residue_tw(std::integral_constant<int, 1>{}, tw64p1);
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        residue_tw(std::integral_constant<int, 2>{}, tw32p);
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        residue_tw(std::integral_constant<int, 3>{}, tw64p3);
+
+        // row statistics for checkacquisition()
+        MaxIdx m; m.v = -1.0; m.k = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < NP; s++) {
+            const int k = lag_of(tid, s);
+            if (k < n) { MaxIdx t; t.v = P[s]; t.k = k; m = better(m, t); }
+        }
+        m = wg_argmax<NT>(m, sd, si, tid);
+        int exs = m.k - nsc2; if (exs < 0) exs += n;
+        int exe = m.k + nsc2; if (exe >= n) exe -= n;
+        double so = 0.0, mo = -1.0;
+#pragma unroll
+        for (int s = 0; s < NP; s++) {
+            const int k = lag_of(tid, s);
+            if (k < n) {
+                const bool outside = (exs <= exe) ? (k < exs || k > exe) : (k < exs && k > exe);
+                if (outside) so += P[s];
+                if (outside || k == 0) mo = fmax(mo, P[s]);    // element 0 seeds maxvd()
+            }
+        }
+        wg_sum_max<NT>(so, mo, sd, tid);
+        if (tid == 0) {
+            GcAcqRow r;
+            r.rowmax = m.v; r.sum_out = so; r.max_out = mo; r.argmax = m.k; r.pad = 0;
+            rows[((size_t)ch * maxintg + it) * maxfreq + bin] = r;
+        }
+        __syncthreads();
+    }
+    if (Pout) {
+#pragma unroll
+        for (int s = 0; s < NP; s++) {
+            const int k = lag_of(tid0, s);
+            if (k < n) Pout[(size_t)bin * n + k] = P[s];
+        }
+    }
+}
+
 // acq_final: one wavefront per channel; the lanes share the bins of an iteration
 __global__ __launch_bounds__(64) void acq_final_kernel(const GcChan *__restrict__ chan, const double *__restrict__ freqs,
                                                        const GcAcqRow *__restrict__ rows,
@@ -527,7 +795,8 @@ void gc_acq_free(gnsscorr_ctx *ctx)
 {
     GcAcqWork *w = ctx->acq;
     if (!w) return;
-    hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->tw32p); hipFree(w->X); hipFree(w->C); hipFree(w->rows);
+    hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->tw32p); hipFree(w->tw64p1); hipFree(w->tw64p3);
+    hipFree(w->X); hipFree(w->C); hipFree(w->rows);
     hipFree(w->iters); hipFree(w->res); hipFree(w->P);
     hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos); hipFree(w->car); hipFree(w->car_overflow);
     delete w;
@@ -542,7 +811,10 @@ static int acq_tables(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&w->tw16k, sizeof(float2) * GC_LH));
     GC_HIP(hipMalloc((void **)&w->tw32k, sizeof(float2) * GC_LH));
     GC_HIP(hipMalloc((void **)&w->tw32p, sizeof(float2) * GC_LH));
+    GC_HIP(hipMalloc((void **)&w->tw64p1, sizeof(float2) * GC_LH));
+    GC_HIP(hipMalloc((void **)&w->tw64p3, sizeof(float2) * GC_LH));
     hipLaunchKernelGGL(tw_init_kernel, dim3(GC_LH / 256), dim3(256), 0, ctx->stream, w->tw16k, w->tw32k, w->tw32p);
+    hipLaunchKernelGGL(tw64_init_kernel, dim3(GC_LH / 256), dim3(256), 0, ctx->stream, w->tw64p1, w->tw64p3);
     GC_HIP(hipGetLastError());
     {
         const int lds = GC_FFT_LDS + 256;
@@ -550,6 +822,7 @@ static int acq_tables(gnsscorr_ctx *ctx)
         GC_HIP(hipFuncSetAttribute((const void *)acq_code_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
         GC_HIP(hipFuncSetAttribute((const void *)acq_corr_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
+        GC_HIP(hipFuncSetAttribute((const void *)acq_corr64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256));
         GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)fft16k_kernel<+1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GC_HIP(hipFuncSetAttribute((const void *)pspec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -565,18 +838,22 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     if (w->C) return GNSSCORR_OK;
     const int nch = ctx->nch;
     w->ngrid = 0; w->maxfreq = 0; w->maxintg = 0;
+    w->L = GC_L;
     w->grid_chan.clear();
     for (int i = 0; i < nch; i++) {
         const GcChan &c = ctx->hchan[i];
-        if (c.nsamp > GC_LH || 2 * c.nsamp > GC_L)
-            return gc_fail(GNSSCORR_EINVAL, "acquisition: nsamp %d needs an FFT longer than 32768", c.nsamp);
+        // the window of 2*nsamp samples must fit the transform: 32768 points up to 16384 samples per code
+        // period, 65536 (20 / 26 Msps front ends) up to 32768
+        if (c.nsamp > GC_L)
+            return gc_fail(GNSSCORR_EINVAL, "acquisition: nsamp %d needs an FFT longer than 65536", c.nsamp);
+        if (c.nsamp > GC_LH) w->L = 2 * GC_L;
         if (c.grid >= w->ngrid) { w->ngrid = c.grid + 1; w->grid_chan.push_back(i); }
         if (c.nfreq > w->maxfreq) w->maxfreq = c.nfreq;
         if (c.intg > w->maxintg) w->maxintg = c.intg;
     }
-    w->X_elems = (size_t)w->ngrid * w->maxintg * w->maxfreq * GC_L;
+    w->X_elems = (size_t)w->ngrid * w->maxintg * w->maxfreq * w->L;
     GC_HIP(hipMalloc((void **)&w->X, sizeof(float2) * w->X_elems));
-    GC_HIP(hipMalloc((void **)&w->C, sizeof(float2) * (size_t)nch * GC_L));
+    GC_HIP(hipMalloc((void **)&w->C, sizeof(float2) * (size_t)nch * w->L));
     GC_HIP(hipMalloc((void **)&w->rows, sizeof(GcAcqRow) * (size_t)nch * w->maxintg * w->maxfreq));
     GC_HIP(hipMalloc((void **)&w->iters, sizeof(int) * nch));
     GC_HIP(hipMalloc((void **)&w->res, sizeof(gnsscorr_acqres_t) * nch));
@@ -593,7 +870,7 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     {
         GcTimed t(ctx, "acq_code");
         hipLaunchKernelGGL(acq_code_kernel, dim3(nch), dim3(GC_FFT_THREADS), GC_FFT_LDS + 256, ctx->stream,
-                           ctx->dchan, w->tw16k, w->tw32p, w->C);
+                           ctx->dchan, w->tw16k, w->tw32p, w->tw64p1, w->tw64p3, w->C, w->L);
     }
     GC_HIP(hipGetLastError());
     int over = 0;
@@ -633,7 +910,7 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
         GcTimed t(ctx, "acq_fwd");
         hipLaunchKernelGGL(acq_fwd_kernel, dim3(w->maxfreq, w->maxintg, w->ngrid), dim3(GC_FFT_THREADS), lds + GC_ACQ_CARLDS,
                            ctx->stream, ctx->dchan, w->d_grid_chan, w->car, w->d_grid_wrpos, w->tw16k, w->tw32p,
-                           w->X, w->maxfreq, w->maxintg);
+                           w->tw64p1, w->tw64p3, w->X, w->maxfreq, w->maxintg, w->L);
     }
     GC_HIP(hipGetLastError());
     hipLaunchKernelGGL(fill_int_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, w->iters,
@@ -641,7 +918,11 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     {
         GcTimed t(ctx, "acq_corr");
         static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
-        if (nt == 1024)
+        if (w->L == 2 * GC_L)
+            hipLaunchKernelGGL(acq_corr64_kernel, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(512), lds + 256,
+                               ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->tw64p1, w->tw64p3, w->X, w->C, w->iters,
+                               w->rows, (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
+        else if (nt == 1024)
             hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(1024), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
@@ -719,9 +1000,14 @@ extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
     }
     // iteration count of the last run is still in w->iters[ch]; rows of this channel are rewritten
     // with identical values
-    hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
-                       ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows, w->P, ch,
-                       w->maxfreq, w->maxintg, 1);
+    if (w->L == 2 * GC_L)
+        hipLaunchKernelGGL(acq_corr64_kernel, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
+                           ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->tw64p1, w->tw64p3, w->X, w->C, w->iters,
+                           w->rows, w->P, ch, w->maxfreq, w->maxintg, 1);
+    else
+        hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
+                           ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows, w->P, ch,
+                           w->maxfreq, w->maxintg, 1);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));

@@ -88,3 +88,47 @@ def test_acquisition_matches_oracle(gc, orc, synth, engine, dtype, f_if):
             P = engine.acq_power(i)
             assert P.shape == (o.nfreq, o.nsamp)
             assert rel_err(P.ravel(), power) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype,f_sf,f_if", [(2, 20e6, 0.0), (1, 20e6, 4.0e6), (2, 26e6, 0.0)])
+def test_acquisition_long_periods_65536_point_transform(gc, orc, synth, engine, dtype, f_sf, f_if):
+    """20 / 26 Msps front ends (ref frontend/stereo_L1G1.ini:5-13: SF 20 MHz, IF 4 MHz real and zero-IF IQ):
+    20000 / 26000 samples per code period, the reference transforms 2*nsamp = 40000 / 52000 points (ref
+    src/sdrinit.c:625), the HIP path 65536.  Decisions identical, power / peak ratio / C/N0 to 1e-4."""
+    nsamp = int(f_sf * 1e-3)
+    prns = [6, 15, 28]                      # 6 and 28 present
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in prns}
+    rng = np.random.default_rng(int(f_sf / 1e6) + dtype)
+    sats = [dict(prn=p, doppler=float(rng.uniform(-4000, 4000)), codephase=float(rng.uniform(0, 1023)),
+                 cn0=float(rng.uniform(45, 49)), phase=float(rng.uniform(0, 6.28))) for p in (6, 28)]
+    nsamples = 14 * nsamp
+    data = synth.make_if(codes, nsamples, f_sf=f_sf, f_if=f_if, dtype=dtype, sats=sats, seed=99 + dtype)
+    engine.ring_create(1, dtype, nsamples)
+    engine.ring_push_raw(1, data, nsamples)
+    chans = [gc.Channel(p, dtype=dtype, f_sf=f_sf, f_if=f_if) for p in prns]
+    assert chans[0].nsamp == nsamp and chans[0].nfft == 2 * nsamp
+    engine.set_channels(chans)
+    wrpos = 12 * nsamp + 333
+    engine.acq_run(wrpos)
+    res = engine.acq_fetch()
+    ring = orc.make_ring(data, nsamples, wrpos)
+    for i, p in enumerate(prns):
+        o = orc.make_chan(p, dtype=dtype, f_sf=f_sf, f_if=f_if)
+        assert o.nsamp == nsamp
+        xc = orc.codespectrum(o)
+        o.xcode = xc.ctypes.data
+        power = np.zeros(o.nfreq * o.nsamp)
+        iters = C.c_int()
+        buffloc = orc.lib().orc_sdracquisition(C.byref(o), C.byref(ring), power.ctypes.data, C.byref(iters))
+        r = res[i]
+        assert r["flagacq"] == o.flagacq == (1 if p in (6, 28) else 0), (p, r, o.acq.peakr)
+        assert r["iters"] == iters.value and r["buffloc"] == buffloc
+        assert r["acqcodei"] == o.acq.acqcodei and r["freqi"] == o.acq.freqi and r["acqfreq"] == o.acq.acqfreq
+        assert abs(r["peakr"] - o.acq.peakr) <= 1e-4 * o.acq.peakr
+        assert abs(r["cn0"] - o.acq.cn0) <= 1e-4 * abs(o.acq.cn0)
+        if p == 6:
+            s = [s for s in sats if s["prn"] == 6][0]
+            assert abs((r["acqfreq"] - f_if) - s["doppler"]) <= 200.0
+            P = engine.acq_power(i)
+            assert P.shape == (o.nfreq, o.nsamp)
+            assert rel_err(P.ravel(), power) <= 1e-4
