@@ -160,8 +160,220 @@ void correlator(const char *data, int dtype, double ti, int n, double freq, doub
     host_rems(phi0, freq, ti, n, coff, s[ns - 1], ti * crate, coden, remc, remp);
 }
 
-// ref src/sdrtrk.c:15-54.  Samples come from the HBM mirror of the ring
-// (front end sdr->ftype) instead of rcvgetbuff().
+// ---- sdrtracking(): concurrent callers share one launch chain ------------------------------------------
+// The reference runs one pthread per channel and every one of them calls sdrtracking() once per code period
+// (ref src/sdrmain.c:144-149,264-265).  One launch chain per call would serialise 32 threads on the GPU
+// queue at ~100 us each; instead the callers that arrive while a chain is in flight are collected and the
+// next chain serves all of them at once (flat combining: whoever finds no leader becomes the leader, takes
+// every queued request, runs expand -> correlate -> finish for the whole set, hands the results back and
+// wakes the others).  Per-channel code blocks stay on the device between calls.
+}   // extern "C" (helpers below are C++)
+
+#include <condition_variable>
+#include <map>
+#include <vector>
+
+namespace {
+
+struct TrkReq {
+    sdrch_t *sdr;
+    uint64_t buffloc;
+    int n;
+    double cI[GNSSCORR_MAXTAPS], cQ[GNSSCORR_MAXTAPS];
+    int rc;
+    bool done;
+    char err[200];
+};
+
+struct CodeSlot { int8_t *dcode = nullptr; long sum = -1; int clen = 0, nedge = 0, pm1 = 0; };
+
+struct TrkCombiner {
+    std::mutex qm;
+    std::condition_variable cv;
+    std::vector<TrkReq *> queue;
+    bool leader = false;
+    std::map<sdrch_t *, CodeSlot> codes;
+    // device / pinned staging for `cap` requests
+    int cap = 0, nseg_cap = 0, ntap_cap = 0;
+    GcChan *dchan = nullptr, *hchan = nullptr;
+    GcTrkPlan *dplan = nullptr, *hplan = nullptr;
+    GcTrkUnit *dunit = nullptr;
+    GcUnitSegs *dsegs = nullptr;
+    GcRound *drounds = nullptr;
+    int *dpartial = nullptr, *doverflow = nullptr;
+    double *dout = nullptr, *hout = nullptr;          // corrI[cap][ntap], corrQ[cap][ntap], sumI, sumQ
+    unsigned long long *dfinish = nullptr;
+};
+TrkCombiner g_cmb;
+
+int cmb_reserve(gnsscorr_ctx *ctx, int k, int nseg, int ntap)
+{
+    TrkCombiner &q = g_cmb;
+    if (k <= q.cap && nseg <= q.nseg_cap && ntap <= q.ntap_cap) return 0;
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(q.dchan); hipFree(q.dplan); hipFree(q.dunit); hipFree(q.dsegs); hipFree(q.drounds); hipFree(q.dpartial);
+    hipFree(q.dout); hipFree(q.dfinish); hipFree(q.doverflow);
+    hipHostFree(q.hchan); hipHostFree(q.hplan); hipHostFree(q.hout);
+    const int cap = k > 64 ? k : 64, ns = nseg > 1 ? nseg : 1, nt = GNSSCORR_MAXTAPS;
+    q.cap = q.nseg_cap = q.ntap_cap = 0;
+    GC_HIP(hipMalloc((void **)&q.dchan, sizeof(GcChan) * cap));
+    GC_HIP(hipMalloc((void **)&q.dplan, sizeof(GcTrkPlan) * cap));
+    GC_HIP(hipMalloc((void **)&q.dunit, sizeof(GcTrkUnit) * cap));
+    GC_HIP(hipMalloc((void **)&q.dsegs, sizeof(GcUnitSegs) * cap));
+    GC_HIP(hipMalloc((void **)&q.drounds, sizeof(GcRound) * cap * ns * GC_MAXR));
+    GC_HIP(hipMalloc((void **)&q.dpartial, sizeof(int) * cap * ns * 2 * nt));
+    GC_HIP(hipMalloc((void **)&q.dout, sizeof(double) * cap * 4 * nt));
+    GC_HIP(hipMalloc((void **)&q.dfinish, sizeof(unsigned long long) * cap * GC_FINISH_SCRATCH));
+    GC_HIP(hipMalloc((void **)&q.doverflow, sizeof(int)));
+    GC_HIP(hipMemsetAsync(q.dfinish, 0, sizeof(unsigned long long) * cap * GC_FINISH_SCRATCH, ctx->stream));
+    GC_HIP(hipMemsetAsync(q.doverflow, 0, sizeof(int), ctx->stream));
+    GC_HIP(hipHostMalloc((void **)&q.hchan, sizeof(GcChan) * cap));
+    GC_HIP(hipHostMalloc((void **)&q.hplan, sizeof(GcTrkPlan) * cap));
+    GC_HIP(hipHostMalloc((void **)&q.hout, sizeof(double) * cap * 4 * nt + 64));
+    q.cap = cap; q.nseg_cap = ns; q.ntap_cap = nt;
+    return 0;
+}
+
+// the channel's code block on the device (uploaded when the code of this sdrch_t is first seen or changes)
+int cmb_code(gnsscorr_ctx *ctx, sdrch_t *sdr, CodeSlot **out)
+{
+    CodeSlot &cs = g_cmb.codes[sdr];
+    long sum = 0;
+    for (int i = 0; i < sdr->clen; i++) sum = sum * 31 + sdr->code[i];
+    if (!cs.dcode || cs.sum != sum || cs.clen != sdr->clen) {
+        if (!cs.dcode) GC_HIP(hipMalloc((void **)&cs.dcode, GC_CODEBLOCK));
+        int8_t block[GC_CODEBLOCK];
+        gc_build_codeblock(sdr->code, sdr->clen, block, &cs.nedge, &cs.pm1);
+        GC_HIP(hipMemcpy(cs.dcode, block, GC_CODEBLOCK, hipMemcpyHostToDevice));
+        cs.sum = sum;
+        cs.clen = sdr->clen;
+    }
+    *out = &cs;
+    return 0;
+}
+
+// one launch chain for a set of requests that share dtype and tap count
+int cmb_run_group(gnsscorr_ctx *ctx, std::vector<TrkReq *> &grp)
+{
+    TrkCombiner &q = g_cmb;
+    const int k = (int)grp.size();
+    const int dtype = grp[0]->sdr->dtype, ntap = 1 + 2 * grp[0]->sdr->trk.corrn;
+    int max_n = 0, smax_max = 0;
+    for (TrkReq *r : grp) {
+        if (r->n > max_n) max_n = r->n;
+        const int sm = r->sdr->trk.corrp[r->sdr->trk.corrn - 1];
+        if (sm > smax_max) smax_max = sm;
+    }
+    const int nseg = gc_trk_nseg(dtype, max_n);
+    int rc = cmb_reserve(ctx, k, nseg, ntap);
+    if (rc) return rc;
+    for (int i = 0; i < k; i++) {
+        sdrch_t *sdr = grp[i]->sdr;
+        const GcRing &ring = ctx->ring[sdr->ftype == FTYPE2 ? 1 : 0];
+        CodeSlot *cs;
+        rc = cmb_code(ctx, sdr, &cs);
+        if (rc) return rc;
+        GcChan &c = q.hchan[i];
+        memset(&c, 0, sizeof(c));
+        c.ring = ring.mem; c.ringlen = ring.ringlen; c.code = cs->dcode;
+        c.dtype = dtype; c.clen = sdr->clen; c.nsamp = grp[i]->n; c.ntap = ntap;
+        c.smax = sdr->trk.corrp[sdr->trk.corrn - 1];
+        c.tapoff[0] = 0;
+        for (int t = 0; t < sdr->trk.corrn; t++) { c.tapoff[1 + 2 * t] = -sdr->trk.corrp[t]; c.tapoff[2 + 2 * t] = sdr->trk.corrp[t]; }
+        c.ti = sdr->ti;
+        c.nedge = cs->nedge; c.pm1 = cs->pm1;
+        GcTrkPlan &p = q.hplan[i];
+        memset(&p, 0, sizeof(p));
+        p.buffloc = grp[i]->buffloc; p.coff = sdr->trk.oldremcode; p.phi0 = sdr->trk.oldremcarr;
+        p.carrfreq = sdr->trk.carrfreq; p.codefreq = sdr->trk.codefreq; p.n = grp[i]->n;
+    }
+    hipStream_t st = ctx->stream;
+    GC_HIP(hipMemcpyAsync(q.dchan, q.hchan, sizeof(GcChan) * k, hipMemcpyHostToDevice, st));
+    GC_HIP(hipMemcpyAsync(q.dplan, q.hplan, sizeof(GcTrkPlan) * k, hipMemcpyHostToDevice, st));
+    rc = gc_launch_trk_expand(st, q.dchan, q.dplan, q.dunit, q.dsegs, nullptr, k, 1, q.drounds, nseg, max_n, q.doverflow);
+    if (rc) return rc;
+    rc = gc_launch_trk_corr(st, q.dchan, q.dunit, q.dsegs, q.drounds, q.dpartial, k, 1, nseg, ntap, dtype, ntap, max_n, smax_max);
+    if (rc) return rc;
+    double *cI = q.dout, *cQ = q.dout + (size_t)q.cap * ntap, *sI = cQ + (size_t)q.cap * ntap, *sQ = sI + (size_t)q.cap * ntap;
+    rc = gc_launch_trk_finish(st, q.dpartial, cI, cQ, sI, sQ, q.dfinish, k, 1, nseg, ntap);
+    if (rc) return rc;
+    int *hover = reinterpret_cast<int *>(q.hout + (size_t)q.cap * 4 * GNSSCORR_MAXTAPS);
+    GC_HIP(hipMemcpyAsync(q.hout, cI, sizeof(double) * k * ntap, hipMemcpyDeviceToHost, st));
+    GC_HIP(hipMemcpyAsync(q.hout + (size_t)k * ntap, cQ, sizeof(double) * k * ntap, hipMemcpyDeviceToHost, st));
+    GC_HIP(hipMemcpyAsync(hover, q.doverflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    if (*hover) {
+        GC_HIP(hipMemsetAsync(q.doverflow, 0, sizeof(int), st));
+        return gc_fail(GNSSCORR_EINVAL, "sdrtracking: a period needs more NCO pieces than the tables hold");
+    }
+    for (int i = 0; i < k; i++) {
+        memcpy(grp[i]->cI, q.hout + (size_t)i * ntap, sizeof(double) * ntap);
+        memcpy(grp[i]->cQ, q.hout + (size_t)(k + i) * ntap, sizeof(double) * ntap);
+    }
+    return 0;
+}
+
+void cmb_run(std::vector<TrkReq *> &batch)
+{
+    gnsscorr_ctx *ctx = gnsscorr_default_ctx();
+    auto fail_all = [&](std::vector<TrkReq *> &v, const char *msg) {
+        for (TrkReq *r : v) { r->rc = -1; snprintf(r->err, sizeof(r->err), "%s", msg); }
+    };
+    if (!ctx) { fail_all(batch, gnsscorr_last_error()); return; }
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail_all(batch, "hipSetDevice"); return; }
+    // groups of equal dtype and tap count (one [TRACK] section per receiver: normally a single group)
+    std::vector<bool> taken(batch.size(), false);
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        std::vector<TrkReq *> grp;
+        for (size_t j = i; j < batch.size(); j++) {
+            if (taken[j]) continue;
+            if (batch[j]->sdr->dtype == batch[i]->sdr->dtype && batch[j]->sdr->trk.corrn == batch[i]->sdr->trk.corrn) {
+                const GcRing &ring = ctx->ring[batch[j]->sdr->ftype == FTYPE2 ? 1 : 0];
+                taken[j] = true;
+                if (!ring.mem || ring.dtype != batch[j]->sdr->dtype) {
+                    batch[j]->rc = -1;
+                    snprintf(batch[j]->err, sizeof(batch[j]->err), "IF ring %d is not mirrored on the GPU", batch[j]->sdr->ftype);
+                    continue;
+                }
+                grp.push_back(batch[j]);
+            }
+        }
+        if (grp.empty()) continue;
+        if (cmb_run_group(ctx, grp)) fail_all(grp, gnsscorr_last_error());
+    }
+}
+
+// enqueue, lead or wait
+void cmb_submit(TrkReq *req)
+{
+    TrkCombiner &q = g_cmb;
+    std::unique_lock<std::mutex> lk(q.qm);
+    q.queue.push_back(req);
+    while (!req->done) {
+        if (!q.leader) {
+            q.leader = true;
+            std::vector<TrkReq *> batch;
+            batch.swap(q.queue);
+            lk.unlock();
+            cmb_run(batch);
+            lk.lock();
+            for (TrkReq *r : batch) r->done = true;
+            q.leader = false;
+            q.cv.notify_all();
+        } else {
+            q.cv.wait(lk);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ref src/sdrtrk.c:15-54.  Samples come from the HBM mirror of the ring (front end sdr->ftype) instead of
+// rcvgetbuff(); concurrent callers are served by one launch chain (above).
 uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt)
 {
     uint64_t bufflocnow;
@@ -172,14 +384,6 @@ uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt)
     unmlock(hreadmtx);
 
     if (bufflocnow > buffloc) {
-        gnsscorr_ctx *ctx = gnsscorr_default_ctx();
-        if (!ctx) { SDRPRINTF("error: sdrtracking: no GPU context (%s)\n", gnsscorr_last_error()); return bufflocnow; }
-        std::lock_guard<std::mutex> lk(ctx->mtx);
-        const GcRing &r = ctx->ring[sdr->ftype == FTYPE2 ? 1 : 0];
-        if (!r.mem || r.dtype != sdr->dtype) {
-            SDRPRINTF("error: sdrtracking: IF ring %d is not mirrored on the GPU\n", sdr->ftype);
-            return bufflocnow;
-        }
         sdr->currnsamp = (int)((sdr->clen - sdr->trk.remcode) / (sdr->trk.codefreq / sdr->f_sf));
 
         // the reference copies 1+2*corrn*sizeof(double) bytes here (:35-36)
@@ -188,18 +392,23 @@ uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt)
         sdr->trk.oldremcode = sdr->trk.remcode;
         sdr->trk.oldremcarr = sdr->trk.remcarr;
 
-        double cI[GNSSCORR_MAXTAPS], cQ[GNSSCORR_MAXTAPS];
-        if (hipSetDevice(ctx->device) != hipSuccess ||
-            corr_unit(ctx, r.mem, r.ringlen, sdr->dtype, sdr->ti, sdr->currnsamp, sdr->trk.carrfreq,
-                      sdr->trk.oldremcarr, sdr->trk.codefreq, sdr->trk.oldremcode, sdr->trk.corrp,
-                      sdr->trk.corrn, sdr->code, sdr->clen, buffloc, cI, cQ)) {
-            SDRPRINTF("error: sdrtracking: %s\n", gnsscorr_last_error());
+        TrkReq req;
+        req.sdr = sdr; req.buffloc = buffloc; req.n = sdr->currnsamp; req.rc = 0; req.done = false; req.err[0] = 0;
+        if (sdr->trk.corrn < 1 || 1 + 2 * sdr->trk.corrn > GNSSCORR_MAXTAPS || sdr->clen < 1 || sdr->clen > 1023 ||
+            sdr->currnsamp < 1) {
+            SDRPRINTF("error: sdrtracking: unsupported shape (corrn %d, code length %d, %d samples)\n", sdr->trk.corrn,
+                      sdr->clen, sdr->currnsamp);
+            return bufflocnow;
+        }
+        cmb_submit(&req);
+        if (req.rc) {
+            SDRPRINTF("error: sdrtracking: %s\n", req.err);
             return bufflocnow;
         }
         // correlator(..., sdr->trk.QQ, sdr->trk.II, ...): the swapped hand-over of :40-43
         const int ntap = 1 + 2 * sdr->trk.corrn;
-        memcpy(sdr->trk.QQ, cI, sizeof(double) * ntap);
-        memcpy(sdr->trk.II, cQ, sizeof(double) * ntap);
+        memcpy(sdr->trk.QQ, req.cI, sizeof(double) * ntap);
+        memcpy(sdr->trk.II, req.cQ, sizeof(double) * ntap);
         host_rems(sdr->trk.oldremcarr, sdr->trk.carrfreq, sdr->ti, sdr->currnsamp, sdr->trk.oldremcode,
                   sdr->trk.corrp[sdr->trk.corrn - 1], sdr->ti * sdr->trk.codefreq, sdr->clen,
                   &sdr->trk.remcode, &sdr->trk.remcarr);

@@ -203,3 +203,150 @@ def test_sdracquisition_then_sdrtracking_like_sdrthread(gc, orc, synth, tmp_path
     L.sdrtracking(C.byref(sdr), ntotal, cnt)
     assert sdr.flagtrk == 0 and sdr.trk.remcode == before
     L.freesdrch(C.byref(sdr))
+
+
+def test_sdrtracking_from_32_concurrent_threads(gc, orc, synth, tmp_path):
+    """The reference's threading model (ref src/sdrmain.c:144-149): one thread per channel, every one of them
+    calling sdrtracking() + cumsumcorr() + pll() + dll() once per code period, concurrently, on its own
+    sdrch_t.  32 channels x 40 periods; every channel equal to the oracle bit for bit; the call rate is
+    printed (1x real time = 32 000 calls/s)."""
+    import threading
+    import time
+    L, O = gc.lib(), orc.lib()
+    nch, nper = 32, 40
+    prns = list(range(1, nch + 1))
+    codes = {p: gc.gencode(p, 1) for p in prns}
+    rng = np.random.default_rng(77)
+    sats = [dict(prn=p, doppler=float(rng.uniform(-4000, 4000)), codephase=float(rng.uniform(0, 1023)),
+                 cn0=46.0, phase=float(rng.uniform(0, 6.28))) for p in prns[::4]]
+    nblocks = 12
+    ntotal = nblocks * 65536
+    data = synth.make_if(codes, ntotal, f_if=4.092e6, dtype=1, sats=sats, seed=23)
+    f = tmp_path / "if32.dat"
+    data.tofile(f)
+    ini = gc.sdrini()
+    ini.fend, ini.useif1, ini.useif2 = 10, 1, 0
+    ini.file1 = str(f).encode()
+    ini.dtype[0], ini.f_sf[0], ini.f_if[0], ini.f_cf[0] = 1, 16.368e6, 4.092e6, 1575.42e6
+    ini.trkcorrn, ini.trkcorrd, ini.trkcorrp = 2, 3, 3
+    for k, v in (("trkdllb", (5.0, 1.0)), ("trkpllb", (30.0, 10.0)), ("trkfllb", (200.0, 50.0))):
+        getattr(ini, k)[0], getattr(ini, k)[1] = v
+    ini.fp1 = None
+    assert L.rcvinit_file(C.byref(ini)) == 0
+    for _ in range(nblocks):
+        L.file_pushtomembuf()
+    sdrs, starts = [], []
+    for i, p in enumerate(prns):
+        sdr = gc.SdrCh()
+        assert L.initsdrch(i + 1, gc.SYS_GPS, p, gc.CTYPE_L1CA, 1, 1, 1575.42e6, 16.368e6, 4.092e6, C.byref(sdr)) == 0
+        sdr.flagacq = 1
+        sdr.acq.acqfreq = 4.092e6 + 200.0 * int(rng.integers(-20, 21))
+        sdr.trk.carrfreq, sdr.trk.codefreq = sdr.acq.acqfreq, sdr.crate
+        sdrs.append(sdr)
+        starts.append(int(rng.integers(0, 16368)))
+    hist = [[] for _ in range(nch)]
+    errs = []
+
+    def worker(i):
+        try:
+            sdr, b = sdrs[i], starts[i]
+            for cnt in range(nper):
+                L.sdrtracking(C.byref(sdr), b, cnt)
+                assert sdr.flagtrk == 1
+                hist[i].append((list(sdr.trk.II[:5]), list(sdr.trk.QQ[:5]), sdr.currnsamp, sdr.trk.remcode, sdr.trk.remcarr))
+                L.cumsumcorr(C.byref(sdr.trk), 1)
+                L.pll(C.byref(sdr), C.byref(sdr.trk.prm1), sdr.ctime)
+                L.dll(C.byref(sdr), C.byref(sdr.trk.prm1), sdr.ctime)
+                L.clearcumsumcorr(C.byref(sdr.trk))
+                b += sdr.currnsamp
+        except Exception as e:          # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    L.sdrtracking(C.byref(gc.SdrCh()), 1 << 60, 0)          # (context creation outside the timed region)
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(nch)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    assert not errs, errs
+    rate = nch * nper / dt
+    print(f"\nsdrtracking() from {nch} threads: {rate:.0f} calls/s = {rate / 32000:.2f} x real time for 32 channels")
+    # every channel against the oracle
+    ring = orc.Ring()
+    big = np.ascontiguousarray(data)
+    ring.buff, ring.ringlen, ring.wrpos = big.ctypes.data, 5000 * 65536, ntotal
+    for i, p in enumerate(prns):
+        o = orc.make_chan(p, dtype=1, f_if=4.092e6, corrn=2, corrd=3, corrp=3)
+        o.acq.acqfreq = sdrs[i].acq.acqfreq
+        o.carrfreq, o.codefreq = o.acq.acqfreq, o.crate
+        b = starts[i]
+        for cnt in range(nper):
+            O.orc_sdrtracking(C.byref(o), C.byref(ring), b)
+            II, QQ, ns, remc, remp = hist[i][cnt]
+            assert ns == o.currnsamp and remc == o.remcode and remp == o.remcarr, (i, cnt)
+            assert II == list(o.II[:5]) and QQ == list(o.QQ[:5]), (i, cnt)
+            O.orc_cumsumcorr(C.byref(o), 1)
+            O.orc_pll(C.byref(o), 0, o.ctime)
+            O.orc_dll(C.byref(o), 0, o.ctime)
+            O.orc_clearcumsumcorr(C.byref(o))
+            b += o.currnsamp
+        assert sdrs[i].trk.carrfreq == o.carrfreq and sdrs[i].trk.codefreq == o.codefreq
+    for sdr in sdrs:
+        L.freesdrch(C.byref(sdr))
+
+
+def test_sdrtracking_call_rate_from_32_pthreads(gc, orc, synth, tmp_path):
+    """The same from 32 pthreads of a C program linked against libgnsscorr.so (tests/host/threads_harness.c) -- the
+    call rate the reference's channel threads would see, no interpreter in the way -- with its per-channel
+    results checked against the oracle (a weighted checksum of every period's sums + the final frequencies)."""
+    import subprocess
+    import sys
+    nch, nper, nblocks = 32, 200, 56
+    prns = list(range(1, nch + 1))
+    codes = {p: gc.gencode(p, 1) for p in prns}
+    rng = np.random.default_rng(78)
+    sats = [dict(prn=p, doppler=float(rng.uniform(-4000, 4000)), codephase=float(rng.uniform(0, 1023)),
+                 cn0=46.0, phase=float(rng.uniform(0, 6.28))) for p in prns[::4]]
+    ntotal = nblocks * 65536
+    data = synth.make_if(codes, ntotal, f_if=4.092e6, dtype=1, sats=sats, seed=24)
+    f = tmp_path / "if32.dat"
+    data.tofile(f)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "erlangnetwork-gnsslib-sdr_amd")
+    exe = str(tmp_path / "threads_harness")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "tests", "host", "threads_harness.c"),
+                           "-L" + pkg, "-lgnsscorr", "-lpthread", "-lm", "-Wl,-rpath," + pkg])
+    out = subprocess.run([exe, str(f), str(nblocks), str(nch), str(nper)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    rate = float([l for l in lines if l.startswith("calls_per_s")][0].split()[1])
+    print(f"\nsdrtracking() from {nch} pthreads: {rate:.0f} calls/s = {rate / 32000:.2f} x real time for 32 channels")
+    got = {int(l.split()[1]): [float(x) for x in l.split()[2:]] for l in lines if l.startswith("chk")}
+    # the harness's deterministic start states
+    seed = 12345
+    O = orc.lib()
+    ring = orc.Ring()
+    big = np.ascontiguousarray(data)
+    ring.buff, ring.ringlen, ring.wrpos = big.ctypes.data, 5000 * 65536, ntotal
+    for i in range(nch):
+        seed = (seed * 1103515245 + 12345) & 0xFFFFFFFF
+        acqfreq = 4.092e6 + 200.0 * (((seed >> 16) % 41) - 20)
+        seed = (seed * 1103515245 + 12345) & 0xFFFFFFFF
+        b = (seed >> 8) % 16368
+        o = orc.make_chan(i + 1, dtype=1, f_if=4.092e6, corrn=2, corrd=3, corrp=3)
+        o.acq.acqfreq = acqfreq
+        o.carrfreq, o.codefreq = acqfreq, o.crate
+        acc = 0.0
+        for cnt in range(nper):
+            O.orc_sdrtracking(C.byref(o), C.byref(ring), b)
+            assert o.flagtrk == 1
+            for t in range(5):
+                acc += o.II[t] * (t + 1) + o.QQ[t] * (t + 7)
+            O.orc_cumsumcorr(C.byref(o), 1)
+            O.orc_pll(C.byref(o), 0, o.ctime)
+            O.orc_dll(C.byref(o), 0, o.ctime)
+            O.orc_clearcumsumcorr(C.byref(o))
+            b += o.currnsamp
+        assert got[i] == [acc, o.carrfreq, o.codefreq], (i, got[i], acc, o.carrfreq, o.codefreq)
