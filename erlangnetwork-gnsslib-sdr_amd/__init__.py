@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNSSCORR_LIB", os.path.join(_HERE, "libgnsscorr.so"))   # override: A/B builds
 
 MAXTAPS = 33
+FMT_STEREO, FMT_RTLSDR = 1, 2
 CTYPE_L1CA, CTYPE_G1, CTYPE_L1SBAS = 1, 20, 27
 SYS_GPS, SYS_SBS, SYS_GLO = 1, 2, 4
 DTYPEI, DTYPEIQ = 1, 2
@@ -49,6 +50,7 @@ class TrkState(C.Structure):
 
 
 MAXTAPS = 33
+FMT_STEREO, FMT_RTLSDR = 1, 2
 
 
 class LoopState(C.Structure):
@@ -181,6 +183,8 @@ def lib():
     L.gnsscorr_ring_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
     L.gnsscorr_ring_push.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.gnsscorr_ring_commit.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    L.gnsscorr_ring_push_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    L.gnsscorr_ring_read.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
     L.gnsscorr_set_channels.argtypes = [C.c_void_p, C.c_int, C.POINTER(ChanDesc)]
     L.gnsscorr_num_channels.argtypes = [C.c_void_p]
     L.gnsscorr_trk_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(TrkState)]
@@ -354,6 +358,16 @@ class Engine:
     def ring_push_raw(self, ftype, raw_bytes, nsamp):
         a = np.ascontiguousarray(raw_bytes, dtype=np.int8)
         _check(self._L.gnsscorr_ring_push(self.h, ftype, a.ctypes.data, nsamp))
+
+    def ring_push_packed(self, fmt, packed, nsamp):
+        """fmt: FMT_STEREO (one byte per sample instant) or FMT_RTLSDR (2*nsamp unsigned bytes)"""
+        a = np.ascontiguousarray(packed, dtype=np.uint8)
+        _check(self._L.gnsscorr_ring_push_packed(self.h, fmt, a.ctypes.data, nsamp))
+
+    def ring_read(self, ftype, buffloc, n, dtype):
+        out = np.empty((n, 2) if dtype == 2 else (n,), np.int8)
+        _check(self._L.gnsscorr_ring_read(self.h, ftype, buffloc, n, out.ctypes.data))
+        return out
 
     def ring_commit(self, ftype, nsamp):
         _check(self._L.gnsscorr_ring_commit(self.h, ftype, nsamp))

@@ -890,6 +890,8 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     GC_HIP(hipSetDevice(ctx->device));
     int rc = acq_prepare(ctx);
     if (rc) return rc;
+    rc = gc_ingest_fence(ctx);
+    if (rc) return rc;
     GcAcqWork *w = ctx->acq;
     std::vector<uint64_t> gw(w->ngrid);
     for (int g = 0; g < w->ngrid; g++) {

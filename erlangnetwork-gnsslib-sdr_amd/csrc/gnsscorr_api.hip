@@ -106,6 +106,7 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->stream_in) hipStreamSynchronize(ctx->stream_in);
     hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
@@ -121,6 +122,12 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
         if (ctx->ev_used[i]) hipEventDestroy(ctx->ev_used[i]);
         if (ctx->ev_corr[i]) hipEventDestroy(ctx->ev_corr[i]);
         if (ctx->ev_fin[i]) hipEventDestroy(ctx->ev_fin[i]);
+    }
+    if (ctx->stream_in) {
+        hipStreamSynchronize(ctx->stream_in);
+        for (int i = 0; i < 2; i++) { hipHostFree(ctx->pin[i]); hipFree(ctx->dstage[i]); if (ctx->ev_pin[i]) hipEventDestroy(ctx->ev_pin[i]); }
+        if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
+        hipStreamDestroy(ctx->stream_in);
     }
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) hipStreamDestroy(ctx->stream3);
@@ -189,23 +196,179 @@ extern "C" int gnsscorr_ring_create(gnsscorr_ctx *ctx, int ftype, int dtype, uin
     return GNSSCORR_OK;
 }
 
+int gc_ingest_fence(gnsscorr_ctx *ctx);
+
+// ---- ingest ----------------------------------------------------------------------------------------------
+#define GC_PIN_BYTES (8u << 20)         // per staging buffer
+
+static int ingest_init(gnsscorr_ctx *ctx)
+{
+    if (ctx->stream_in) return GNSSCORR_OK;
+    GC_HIP(hipStreamCreateWithFlags(&ctx->stream_in, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        GC_HIP(hipHostMalloc((void **)&ctx->pin[i], GC_PIN_BYTES));
+        GC_HIP(hipMalloc((void **)&ctx->dstage[i], GC_PIN_BYTES));
+        GC_HIP(hipEventCreateWithFlags(&ctx->ev_pin[i], hipEventDisableTiming));
+    }
+    GC_HIP(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+    return GNSSCORR_OK;
+}
+
+// a free staging slot (waits for the transfer that last used it, never for the compute stream)
+static int ingest_slot(gnsscorr_ctx *ctx, int *slot)
+{
+    const int s = ctx->pin_next;
+    ctx->pin_next ^= 1;
+    if (ctx->pin_busy[s]) GC_HIP(hipEventSynchronize(ctx->ev_pin[s]));
+    ctx->pin_busy[s] = false;
+    *slot = s;
+    return GNSSCORR_OK;
+}
+
+// the compute stream reads the ring: order it behind the last transfer
+int gc_ingest_fence(gnsscorr_ctx *ctx)
+{
+    if (ctx->in_pending) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+    return GNSSCORR_OK;
+}
+
+// ring bytes [pos, pos + bytes) <- device or pinned source, split at the end of the ring
+static int ring_write(gnsscorr_ctx *ctx, GcRing *r, uint64_t bytepos, const void *src, uint64_t bytes, hipMemcpyKind kind)
+{
+    const uint64_t rb = (uint64_t)r->dtype * r->ringlen;
+    const uint64_t pos = bytepos % rb;
+    const uint64_t first = pos + bytes <= rb ? bytes : rb - pos;
+    GC_HIP(hipMemcpyAsync(r->mem + pos, src, first, kind, ctx->stream_in));
+    if (first < bytes) GC_HIP(hipMemcpyAsync(r->mem, (const int8_t *)src + first, bytes - first, kind, ctx->stream_in));
+    return GNSSCORR_OK;
+}
+
 extern "C" int gnsscorr_ring_push(gnsscorr_ctx *ctx, int ftype, const void *host, uint64_t nsamp)
 {
     GcRing *r = ring_of(ctx, ftype);
     if (!r || !r->mem) return gc_fail(GNSSCORR_ESTATE, "ring_push: ring %d not created", ftype);
     if (nsamp > r->ringlen) return gc_fail(GNSSCORR_EINVAL, "ring_push: chunk larger than the ring");
+    if (!host && nsamp) return gc_fail(GNSSCORR_EINVAL, "ring_push: null host buffer");
     GC_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    int rc = ingest_init(ctx);
+    if (rc) return rc;
     const uint64_t d = (uint64_t)r->dtype;
-    const uint64_t pos = r->wrpos % r->ringlen;
-    const uint64_t first = (pos + nsamp <= r->ringlen) ? nsamp : r->ringlen - pos;
     const int8_t *h = (const int8_t *)host;
-    GC_HIP(hipMemcpyAsync(r->mem + d * pos, h, d * first, hipMemcpyHostToDevice, ctx->stream));
-    if (first < nsamp)
-        GC_HIP(hipMemcpyAsync(r->mem, h + d * first, d * (nsamp - first), hipMemcpyHostToDevice,
-                              ctx->stream));
-    // the host buffer may be reused by the caller as soon as we return
-    GC_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t done = 0, total = d * nsamp;
+    while (done < total) {
+        const uint64_t piece = total - done < GC_PIN_BYTES ? total - done : GC_PIN_BYTES;
+        int s;
+        rc = ingest_slot(ctx, &s);
+        if (rc) return rc;
+        memcpy(ctx->pin[s], h + done, piece);           // the caller's buffer is free again after this
+        rc = ring_write(ctx, r, d * r->wrpos + done, ctx->pin[s], piece, hipMemcpyHostToDevice);
+        if (rc) return rc;
+        GC_HIP(hipEventRecord(ctx->ev_pin[s], ctx->stream_in));
+        ctx->pin_busy[s] = true;
+        done += piece;
+    }
+    GC_HIP(hipEventRecord(ctx->ev_in, ctx->stream_in));
+    ctx->in_pending = true;
     r->wrpos += nsamp;
+    return GNSSCORR_OK;
+}
+
+// ref src/rcv/stereo/stereo.c:160-205 (lut1 / lut2) and src/rcv/rtlsdr/rtlsdr.c:136-143
+__global__ void unpack_stereo_kernel(const uint8_t *__restrict__ src, uint64_t n, int8_t *__restrict__ r1, uint64_t len1,
+                                     uint64_t pos1, int8_t *__restrict__ r2, uint64_t len2, uint64_t pos2)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = src[i];
+    // BASELUT1 = {-3,-1,+1,+3}; BASELUT2 = {+1,+3,+5,+7,-7,-5,-3,-1}
+    if (r1) r1[(pos1 + i) % len1] = (int8_t)(2 * (int)((b >> 6) & 3) - 3);
+    if (r2) {
+        const int vi = (b >> 3) & 7, vq = b & 7;
+        const uint64_t k = (pos2 + i) % len2;
+        r2[2 * k] = (int8_t)(vi < 4 ? 2 * vi + 1 : 2 * vi - 15);
+        r2[2 * k + 1] = (int8_t)(vq < 4 ? 2 * vq + 1 : 2 * vq - 15);
+    }
+}
+
+__global__ void unpack_rtlsdr_kernel(const uint8_t *__restrict__ src, uint64_t nbytes, int8_t *__restrict__ ring,
+                                     uint64_t ringbytes, uint64_t bytepos)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbytes) return;
+    // (char)(buf[i] - 127.5): the double is truncated toward zero
+    const int v = (int)src[i];
+    ring[(bytepos + i) % ringbytes] = (int8_t)(v >= 128 ? v - 128 : v - 127);
+}
+
+extern "C" int gnsscorr_ring_push_packed(gnsscorr_ctx *ctx, int format, const void *host, uint64_t nsamp)
+{
+    if (!ctx || (!host && nsamp)) return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: bad arguments");
+    if (format != GNSSCORR_FMT_STEREO && format != GNSSCORR_FMT_RTLSDR)
+        return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: format %d", format);
+    GcRing *r1 = &ctx->ring[0], *r2 = &ctx->ring[1];
+    if (format == GNSSCORR_FMT_STEREO) {
+        if (!r1->mem && !r2->mem) return gc_fail(GNSSCORR_ESTATE, "ring_push_packed: no ring created");
+        if (r1->mem && r1->dtype != 1) return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: Stereo front end 1 is real (ring 1 must be dtype 1)");
+        if (r2->mem && r2->dtype != 2) return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: Stereo front end 2 is IQ (ring 2 must be dtype 2)");
+        if ((r1->mem && nsamp > r1->ringlen) || (r2->mem && nsamp > r2->ringlen))
+            return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: chunk larger than the ring");
+    } else {
+        if (!r1->mem || r1->dtype != 2) return gc_fail(GNSSCORR_ESTATE, "ring_push_packed: RTL-SDR feeds ring 1 as IQ (dtype 2)");
+        if (nsamp > r1->ringlen) return gc_fail(GNSSCORR_EINVAL, "ring_push_packed: chunk larger than the ring");
+    }
+    GC_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    int rc = ingest_init(ctx);
+    if (rc) return rc;
+    const uint8_t *h = (const uint8_t *)host;
+    const uint64_t total = format == GNSSCORR_FMT_STEREO ? nsamp : 2 * nsamp;       // packed bytes
+    uint64_t done = 0;
+    while (done < total) {
+        const uint64_t piece = total - done < GC_PIN_BYTES ? total - done : GC_PIN_BYTES;
+        int s;
+        rc = ingest_slot(ctx, &s);
+        if (rc) return rc;
+        memcpy(ctx->pin[s], h + done, piece);
+        GC_HIP(hipMemcpyAsync(ctx->dstage[s], ctx->pin[s], piece, hipMemcpyHostToDevice, ctx->stream_in));
+        const unsigned blocks = (unsigned)((piece + 255) / 256);
+        if (format == GNSSCORR_FMT_STEREO)
+            hipLaunchKernelGGL(unpack_stereo_kernel, dim3(blocks), dim3(256), 0, ctx->stream_in, ctx->dstage[s], piece,
+                               r1->mem, r1->mem ? r1->ringlen : 1, r1->wrpos + done, r2->mem, r2->mem ? r2->ringlen : 1,
+                               r2->wrpos + done);
+        else
+            hipLaunchKernelGGL(unpack_rtlsdr_kernel, dim3(blocks), dim3(256), 0, ctx->stream_in, ctx->dstage[s], piece,
+                               r1->mem, 2 * r1->ringlen, 2 * r1->wrpos + done);
+        GC_HIP(hipGetLastError());
+        GC_HIP(hipEventRecord(ctx->ev_pin[s], ctx->stream_in));
+        ctx->pin_busy[s] = true;
+        done += piece;
+    }
+    GC_HIP(hipEventRecord(ctx->ev_in, ctx->stream_in));
+    ctx->in_pending = true;
+    if (format == GNSSCORR_FMT_STEREO) {
+        if (r1->mem) r1->wrpos += nsamp;
+        if (r2->mem) r2->wrpos += nsamp;
+    } else {
+        r1->wrpos += nsamp;
+    }
+    return GNSSCORR_OK;
+}
+
+extern "C" int gnsscorr_ring_read(gnsscorr_ctx *ctx, int ftype, uint64_t buffloc, int n, void *host)
+{
+    GcRing *r = ring_of(ctx, ftype);
+    if (!r || !r->mem) return gc_fail(GNSSCORR_ESTATE, "ring_read: ring %d not created", ftype);
+    if (n <= 0 || (uint64_t)n > r->ringlen || !host) return gc_fail(GNSSCORR_EINVAL, "ring_read: n %d", n);
+    GC_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (ctx->in_pending) GC_HIP(hipEventSynchronize(ctx->ev_in));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    // ref src/sdrrcv.c:508-521
+    const uint64_t d = (uint64_t)r->dtype, rb = d * r->ringlen, pos = (d * buffloc) % rb, nb = d * (uint64_t)n;
+    const uint64_t first = pos + nb <= rb ? nb : rb - pos;
+    GC_HIP(hipMemcpy(host, r->mem + pos, first, hipMemcpyDeviceToHost));
+    if (first < nb) GC_HIP(hipMemcpy((int8_t *)host + first, r->mem, nb - first, hipMemcpyDeviceToHost));
     return GNSSCORR_OK;
 }
 
@@ -213,6 +376,7 @@ extern "C" int gnsscorr_ring_commit(gnsscorr_ctx *ctx, int ftype, uint64_t nsamp
 {
     GcRing *r = ring_of(ctx, ftype);
     if (!r || !r->mem) return gc_fail(GNSSCORR_ESTATE, "ring_commit: ring %d not created", ftype);
+    std::lock_guard<std::mutex> lk(ctx->mtx);
     r->wrpos += nsamp;
     return GNSSCORR_OK;
 }
@@ -434,6 +598,8 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipSetDevice(ctx->device));
     int rc = ensure_trk_buffers(ctx, nepoch);
     if (rc) return rc;
+    rc = gc_ingest_fence(ctx);
+    if (rc) return rc;
     // ---- planner: use the look-ahead plan if it matches, else plan now ----
     // plan = the sequential NCO chain per channel, expand = the per-unit constants of that plan; both
     // run on the planner stream into slot buffers, ev_plan[slot] marks them ready
@@ -564,6 +730,8 @@ extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
     if (!ctx->nch) return gc_fail(GNSSCORR_ESTATE, "trk_run_loop: no channels set");
     GC_HIP(hipSetDevice(ctx->device));
     int rc = ensure_trk_buffers(ctx, nperiod);
+    if (rc) return rc;
+    rc = gc_ingest_fence(ctx);
     if (rc) return rc;
     // the look-ahead planner of the batched interface works on the same state: stop it, drop its plan
     if (ctx->ahead_valid || ctx->fin_pending[0] || ctx->fin_pending[1]) { rc = loop_quiesce(ctx); if (rc) return rc; }

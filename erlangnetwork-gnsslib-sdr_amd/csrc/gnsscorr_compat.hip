@@ -322,6 +322,7 @@ void cmb_run(std::vector<TrkReq *> &batch)
     if (!ctx) { fail_all(batch, gnsscorr_last_error()); return; }
     std::lock_guard<std::mutex> lk(ctx->mtx);
     if (hipSetDevice(ctx->device) != hipSuccess) { fail_all(batch, "hipSetDevice"); return; }
+    if (gc_ingest_fence(ctx)) { fail_all(batch, gnsscorr_last_error()); return; }      // behind the grabber's last block
     // groups of equal dtype and tap count (one [TRACK] section per receiver: normally a single group)
     std::vector<bool> taken(batch.size(), false);
     for (size_t i = 0; i < batch.size(); i++) {

@@ -33,6 +33,17 @@ struct gnsscorr_ctx {
 
     GcRing ring[2];
 
+    // ingest: copy stream + two pinned staging buffers (and device staging for packed formats); ev_in marks
+    // the last transfer, the compute stream waits on it before it reads the ring
+    hipStream_t stream_in = nullptr;
+    int8_t *pin[2] = {nullptr, nullptr};
+    uint8_t *dstage[2] = {nullptr, nullptr};
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    int pin_next = 0;
+    hipEvent_t ev_in = nullptr;
+    bool in_pending = false;
+
     // channels
     int nch = 0;
     std::vector<GcChan> hchan;
@@ -114,3 +125,4 @@ struct GcTimed {
 };
 
 void gc_acq_free(gnsscorr_ctx *ctx);
+int gc_ingest_fence(gnsscorr_ctx *ctx);      // orders the compute stream behind the last ring transfer

@@ -544,6 +544,10 @@ uint64_t sdracquisition(sdrch_t *sdr, double *power)
     uint64_t buffloc = wrpos - (uint64_t)(sdr->acq.intg + 1) * sdr->nsamp;
 
     gnsscorr_ctx *def = gnsscorr_default_ctx();
+    if (def) {      // the private engine shares the default context's ring: its last block must have landed
+        std::lock_guard<std::mutex> lk(def->mtx);
+        if (def->in_pending) hipEventSynchronize(def->ev_in);
+    }
     gnsscorr_ctx *eng = def ? acq_engine(sdr, def) : nullptr;
     gnsscorr_acqres_t r;
     if (!eng || gnsscorr_acq_run(eng, wrpos) || gnsscorr_acq_fetch(eng, &r)) {

@@ -64,9 +64,28 @@ int  gnsscorr_sync(gnsscorr_ctx *ctx);
 int  gnsscorr_ring_create(gnsscorr_ctx *ctx, int ftype, int dtype,
                           uint64_t ringlen, void *devmem);
 /* append nsamp samples from host memory (what file_pushtomembuf's fread
- * delivers, ref src/sdrrcv.c:469-495) and advance the write position */
+ * delivers, ref src/sdrrcv.c:469-495) and advance the write position.  A chunk
+ * may not exceed the ring; chunks of any size are staged piecewise. */
 int  gnsscorr_ring_push(gnsscorr_ctx *ctx, int ftype, const void *host,
                         uint64_t nsamp);
+/* The same for a front end's packed byte stream, expanded on the device on its way into the ring(s):
+ *   GNSSCORR_FMT_STEREO  NSL Stereo: one byte per sample instant, bits 7-6 = front end 1 (real, {-3,-1,+1,+3}),
+ *                        bits 5-3 / 2-0 = front end 2 I / Q ({+1,+3,+5,+7,-7,-5,-3,-1}) -- ref
+ *                        src/rcv/stereo/stereo.c:160-205.  Feeds ring 1 (dtype 1) and ring 2 (dtype 2), whichever
+ *                        exist, nsamp samples each.
+ *   GNSSCORR_FMT_RTLSDR  RTL-SDR: unsigned 8-bit I, Q pairs, (char)(value - 127.5) -- ref
+ *                        src/rcv/rtlsdr/rtlsdr.c:136-143.  Feeds ring 1 (dtype 2) from 2*nsamp bytes.
+ * Both push calls return as soon as the host buffer may be reused; the transfer runs on a copy stream of
+ * the context's own behind pinned staging buffers and never waits for (or stalls) the compute stream --
+ * tracking / acquisition calls issued afterwards are ordered behind it. */
+#define GNSSCORR_FMT_STEREO 1
+#define GNSSCORR_FMT_RTLSDR 2
+int  gnsscorr_ring_push_packed(gnsscorr_ctx *ctx, int format, const void *host,
+                               uint64_t nsamp);
+/* rcvgetbuff() on the HBM ring (ref src/sdrrcv.c:406-463,505-532): n samples from sample index buffloc,
+ * wrapped like file_getbuff(); synchronises */
+int  gnsscorr_ring_read(gnsscorr_ctx *ctx, int ftype, uint64_t buffloc, int n,
+                        void *host);
 /* the ring memory was filled by someone else (RCCL, a kernel): advance only */
 int  gnsscorr_ring_commit(gnsscorr_ctx *ctx, int ftype, uint64_t nsamp);
 uint64_t gnsscorr_ring_wrpos(gnsscorr_ctx *ctx, int ftype);

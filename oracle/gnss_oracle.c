@@ -675,3 +675,26 @@ int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc
     *buffloc += (uint64_t)ch->currnsamp;
     return 1;
 }
+
+/* ref src/rcv/stereo/stereo.c:160-205 */
+void orc_stereo_exp(const unsigned char *buf, int n, int dtype, signed char *expbuf)
+{
+    static const signed char base1[4] = {-3, -1, +1, +3};                  /* 2 bits */
+    static const signed char base2[8] = {+1, +3, +5, +7, -7, -5, -3, -1};  /* 3 bits */
+    int i;
+    if (dtype == 1) {
+        for (i = 0; i < n; i++) expbuf[i] = base1[(buf[i] >> 6) & 0x03];
+    } else {
+        for (i = 0; i < n; i++) {
+            expbuf[2 * i]     = base2[(buf[i] >> 3) & 0x07];
+            expbuf[2 * i + 1] = base2[buf[i] & 0x07];
+        }
+    }
+}
+
+/* ref src/rcv/rtlsdr/rtlsdr.c:136-143 */
+void orc_rtlsdr_exp(const unsigned char *buf, int n, signed char *expbuf)
+{
+    int i;
+    for (i = 0; i < n; i++) expbuf[i] = (signed char)((buf[i] - 127.5));
+}

@@ -156,6 +156,11 @@ void orc_dll(orc_chan_t *ch, int prm, double dt);
  * *buffloc += currnsamp.  Returns ch->flagtrk. */
 int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc);
 
+/* front-end sample expansion: ref src/rcv/stereo/stereo.c:160-205 (dtype 1: front end 1 from bits 7-6,
+ * dtype 2: front end 2 I/Q from bits 5-3 / 2-0) and src/rcv/rtlsdr/rtlsdr.c:136-143 */
+void orc_stereo_exp(const unsigned char *buf, int n, int dtype, signed char *expbuf);
+void orc_rtlsdr_exp(const unsigned char *buf, int n, signed char *expbuf);
+
 #ifdef __cplusplus
 }
 #endif

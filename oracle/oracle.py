@@ -85,6 +85,8 @@ def lib():
     L.orc_pll.argtypes = [C.POINTER(Chan), i, d]
     L.orc_dll.argtypes = [C.POINTER(Chan), i, d]
     L.orc_sdrthread_step.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.POINTER(C.c_uint64)]
+    L.orc_stereo_exp.argtypes = [vp, i, i, vp]
+    L.orc_rtlsdr_exp.argtypes = [vp, i, vp]
     _lib = L
     return L
 
