@@ -18,9 +18,9 @@ Contract (one JSON line on rank 0):
           "rooflines" for the others; "cpu_baseline": the CPU oracle on the host cores.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling in channels -- every
-rank tracks its own 32 channels on the same IF stream; rank 0 owns the stream and each step's
-chunk is broadcast once over RCCL/xGMI into every rank's HBM ring (double buffered against the
-correlators).
+rank tracks its own 32 channels on the same IF stream; rank 0 owns the stream and every chunk is
+broadcast once over RCCL/xGMI into every rank's HBM ring, two chunks ahead of the batch that is being
+correlated (ShardedEngine, erlangnetwork-gnsslib-sdr_amd/multigpu.py).
 """
 import argparse
 import ctypes as C
@@ -206,29 +206,33 @@ def main():
             dist.init_process_group(backend)
 
     E = args.epochs
-    # HBM ring = two chunks of E code periods; while one is correlated the next one lands in the
-    # other half.  Rank 0 owns the IF stream (one synthetic chunk, repeated).
+    mg = importlib.import_module("erlangnetwork_gnsslib_sdr_amd.multigpu")
+    # HBM ring = four chunks of E code periods (ShardedEngine: while a batch is correlated in two of them the
+    # chunk after next lands in another, the fourth absorbs code-rate drift).  Rank 0 owns the IF stream (one
+    # synthetic chunk, repeated).
     chunk = E * NSAMP                               # samples; 2*chunk bytes is a multiple of 16
-    ringlen = 2 * chunk
+    ringlen = 4 * chunk
     if rank == 0:
         data, sats = make_signal(gc, synth, E, args.seed)
-        host = np.concatenate([data, data], axis=0)
+        host = np.concatenate([data, data, data, data], axis=0)
     else:
         host, sats = None, None
 
     stream = torch.cuda.current_stream()
     eng = gc.Engine(dev_index, stream=stream.cuda_stream)
     ring_t = torch.zeros(ringlen * 2, dtype=torch.int8, device=dev)         # the HBM ring of this rank
-    eng.ring_create(1, 2, ringlen, ring_t.data_ptr())
-    if rank == 0:
-        ring_t.copy_(torch.from_numpy(host.reshape(-1)).to(dev))
-    if world > 1:
-        dist.broadcast(ring_t, src=0)
-    torch.cuda.synchronize()
-    eng.ring_commit(1, ringlen)
-
     chans = channel_set(gc, rank)
-    eng.set_channels(chans)
+    se = mg.ShardedEngine(eng, ring_t, chans, chunk, 2, dist=dist, rank=rank, world=world, strong=False)
+    chunk_dev = None
+    if rank == 0:
+        chunk_dev = torch.from_numpy(data.reshape(-1)).to(dev)      # the stream's (repeating) chunk, resident in HBM
+        ring_t.copy_(torch.from_numpy(host.reshape(-1)).to(dev))
+    # two chunks in every ring before the first batch
+    se.feed(chunk_dev, resident=True)
+    se.feed(chunk_dev, resident=True)
+    se.wait()
+    torch.cuda.synchronize()
+
     rng = np.random.default_rng(args.seed + 17 * rank)
     acq_hist = 11 * NSAMP
     states0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)),
@@ -243,27 +247,18 @@ def main():
         torch.cuda.synchronize()
 
     # ---- tracking leg (primary) -------------------------------------------
-    chunk_bytes = chunk * 2
-    pending = [None]
-
     def step(i):
-        # The channels walk through the ring (state stays on the device); the IF chunk of the next
-        # step is broadcast from rank 0 into the idle half of every rank's ring while this step's
-        # half is correlated (one RCCL broadcast per epoch batch, ref SURVEY 8e).
-        if dist is not None:
-            if pending[0] is not None:
-                pending[0].wait()
-            nxt = (i + 1) % 2
-            pending[0] = dist.broadcast(ring_t[nxt * chunk_bytes:(nxt + 1) * chunk_bytes], src=0, async_op=True)
+        # The channels walk through the ring (state stays on the device).  Per launch: the chunk after next
+        # starts travelling from rank 0 into every rank's ring (one RCCL broadcast per epoch batch, ref SURVEY
+        # 8e; on one GPU the repeating chunk is already in place and only the write position moves), then
+        # the batch over the chunks already received is launched.
         for _ in range(args.inner):
-            eng.trk_run(E)
+            se.step(E, chunk_dev, resident=True)
 
     log("tracking leg: warm-up")
     for i in range(args.warmup):
         step(i)
-    if pending[0] is not None:
-        pending[0].wait()
-        pending[0] = None
+    se.wait()
     barrier()
     eng.timing(not os.environ.get("BENCH_NOTIMING"))      # (debug) per-kernel HIP events off
     eng.timing_reset()
@@ -271,8 +266,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    if pending[0] is not None:
-        pending[0].wait()
+    se.wait()
     barrier()
     dt = time.perf_counter() - t0
     eng.timing(False)

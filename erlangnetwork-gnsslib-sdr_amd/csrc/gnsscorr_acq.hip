@@ -901,6 +901,9 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
         if (wp < (uint64_t)(c.intg + 1) * c.nsamp)
             return gc_fail(GNSSCORR_ESTATE, "acq_run: ring %d holds %llu samples, %llu needed", ft,
                            (unsigned long long)wp, (unsigned long long)((uint64_t)(c.intg + 1) * c.nsamp));
+        if (c.ringlen < (uint64_t)(c.intg + 1) * c.nsamp)
+            return gc_fail(GNSSCORR_EINVAL, "acq_run: ring %d (%llu samples) is shorter than the %d code periods the search looks back",
+                           ft, (unsigned long long)c.ringlen, c.intg + 1);
         gw[g] = wp;
     }
     // pageable source: the copy is staged before the call returns

@@ -99,6 +99,9 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
         hipFree(ctx->dnsamp2[i]); ctx->dnsamp2[i] = nullptr;
     }
     hipFree(ctx->dnco_overflow); ctx->dnco_overflow = nullptr;
+    hipFree(ctx->dring_viol); ctx->dring_viol = nullptr;
+    hipFree(ctx->dwrpos); ctx->dwrpos = nullptr;
+    ctx->wrpos_sent[0] = ctx->wrpos_sent[1] = ~0ull;
     ctx->plan_cap = 0;
 }
 
@@ -439,10 +442,17 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
         for (int k = 0; k < c.corrn; k++)
             if (c.corrp[k] <= 0 || (k && c.corrp[k] <= c.corrp[k - 1]))
                 return gc_fail(GNSSCORR_EINVAL, "channel %d: corrp must be positive and increasing", i);
+        if (c.corrp[c.corrn - 1] > 64)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: outermost tap at %d samples (<= 64 supported)", i, c.corrp[c.corrn - 1]);
         const GcRing &r = ctx->ring[c.ftype - 1];
         if (!r.mem) return gc_fail(GNSSCORR_ESTATE, "channel %d: ring %d not created", i, c.ftype);
         if (r.dtype != c.dtype)
             return gc_fail(GNSSCORR_EINVAL, "channel %d: dtype %d but ring %d holds dtype %d", i, c.dtype, c.ftype, r.dtype);
+        // a code period (the reference's scratch is nsamp + 100 samples, ref src/sdrtrk.c:23) plus the 16-byte
+        // groups around it must fit the ring once; acquisition looks (intg + 1) periods back
+        if (r.ringlen < (uint64_t)c.nsamp + 100 + 32 / c.dtype)
+            return gc_fail(GNSSCORR_EINVAL, "channel %d: ring %d (%llu samples) is shorter than a code period (%d + 100 + %d)",
+                           i, c.ftype, (unsigned long long)r.ringlen, c.nsamp, 32 / c.dtype);
     }
     GC_HIP(hipStreamSynchronize(ctx->stream));
     gc_acq_free(ctx);
@@ -587,6 +597,9 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     }
     GC_HIP(hipMalloc((void **)&ctx->dnco_overflow, sizeof(int)));
     GC_HIP(hipMemsetAsync(ctx->dnco_overflow, 0, sizeof(int), ctx->stream));
+    GC_HIP(hipMalloc((void **)&ctx->dring_viol, sizeof(int)));
+    GC_HIP(hipMemsetAsync(ctx->dring_viol, 0, sizeof(int), ctx->stream));
+    GC_HIP(hipMalloc((void **)&ctx->dwrpos, sizeof(uint64_t) * ctx->nch));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -636,9 +649,18 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         rc = plan_into(slot);
         if (rc) return rc;
     }
-    ctx->ahead_valid = false;
-    ctx->state_cur ^= 1;               // the plan's output state is now the committed one
     if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
+    // the planned periods against what the rings hold now
+    if (ctx->wrpos_sent[0] != ctx->ring[0].wrpos || ctx->wrpos_sent[1] != ctx->ring[1].wrpos) {
+        std::vector<uint64_t> wp(ctx->nch);
+        for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
+        GC_HIP(hipMemcpyAsync(ctx->dwrpos, wp.data(), sizeof(uint64_t) * ctx->nch, hipMemcpyHostToDevice, ctx->stream));
+        GC_HIP(hipStreamSynchronize(ctx->stream));      // (wp is a local; only when the write position moved)
+        ctx->wrpos_sent[0] = ctx->ring[0].wrpos;
+        ctx->wrpos_sent[1] = ctx->ring[1].wrpos;
+    }
+    rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], ctx->dwrpos, ctx->nch, nepoch, ctx->dring_viol);
+    if (rc) return rc;
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
     if (!ctx->stream2 && ctx->fin_pending[slot]) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[slot], 0));
@@ -650,6 +672,9 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         if (rc) return rc;
     }
     if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_corr[slot], ctx->stream));     // slot buffers consumed, partials ready
+    // every launch of the batch was issued: only now the plan's output state becomes the committed one
+    ctx->ahead_valid = false;
+    ctx->state_cur ^= 1;
     ctx->plan_slot ^= 1;
     // ---- look ahead: plan the next batch of the same length while this one is correlated ----
     if (ctx->stream2 && !ctx->state_touched) {
@@ -786,7 +811,13 @@ extern "C" int gnsscorr_trk_fetch_log(gnsscorr_ctx *ctx, gnsscorr_trklog_t *log,
 // carrier that visits more than GC_NCAR binades) were not correlated: say so instead of handing out zeros.
 static int nco_check(gnsscorr_ctx *ctx)
 {
-    int n = 0;
+    int n = 0, v = 0;
+    GC_HIP(hipMemcpy(&v, ctx->dring_viol, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) {
+        GC_HIP(hipMemset(ctx->dring_viol, 0, sizeof(int)));
+        return gc_fail(GNSSCORR_ESTATE, "tracking: %d (channel, period) units lay outside what the IF ring holds "
+                       "(beyond the write position, or overwritten since): their sums are not the stream's", v);
+    }
     GC_HIP(hipMemcpy(&n, ctx->dnco_overflow, sizeof(int), hipMemcpyDeviceToHost));
     if (!n) return GNSSCORR_OK;
     GC_HIP(hipMemset(ctx->dnco_overflow, 0, sizeof(int)));

@@ -1524,6 +1524,30 @@ int gc_launch_trk_loop(hipStream_t st, const GcChan *chan, GcTrkState *state, gn
     return gc_fail(GNSSCORR_EINVAL, "trk_loop: dtype %d not 1 or 2", dtype);
 }
 
+// Every planned period must lie in what its ring holds: written already (the reference waits for
+// bufflocnow > buffloc before it tracks a period, ref src/sdrtrk.c:26-30) and not yet overwritten (the
+// reference stops on a buffer overrun, ref src/sdrrcv.c:325-349).  Counts the periods that do not.
+__global__ void trk_ringcheck_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
+                                     const uint64_t *__restrict__ wrpos, int nch, int nepoch, int *__restrict__ viol)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nch * nepoch) return;
+    const int ch = i / nepoch;
+    const GcTrkPlan p = plan[i];
+    if (p.n <= 0) return;
+    const uint64_t wp = wrpos[ch], rl = chan[ch].ringlen;
+    if (p.buffloc + (uint64_t)p.n > wp || (wp > rl && p.buffloc < wp - rl)) atomicAdd(viol, 1);
+}
+
+int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const uint64_t *wrpos, int nch,
+                            int nepoch, int *viol)
+{
+    const int total = nch * nepoch;
+    hipLaunchKernelGGL(trk_ringcheck_kernel, dim3((total + 255) / 256), dim3(256), 0, st, chan, plan, wrpos, nch, nepoch, viol);
+    GC_HIP(hipGetLastError());
+    return 0;
+}
+
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
                          double *sumQ, unsigned long long *scratch, int nch, int nepoch, int nseg, int ntap)
 {

@@ -89,8 +89,6 @@ def test_gps_plus_glonass_on_two_streams(gc, orc, synth, engine):
     states = [dict(carrfreq=res[i]["acqfreq"], codefreq=chans[i].crate, remcode=0.0, remcarr=0.0,
                    buffloc=res[i]["buffloc"]) if i in live else
               dict(carrfreq=0.0, codefreq=chans[i].crate, remcode=0.5, remcarr=0.0, buffloc=100) for i in range(len(chans))]
-    engine.ring_commit(1, nsamp)
-    engine.ring_commit(2, nsamp)
     engine.trk_set_state(states)
     nep = 4
     engine.trk_run(nep)
@@ -146,8 +144,6 @@ def test_fine_doppler_grid_and_10ms_sums(gc, orc, synth, engine):
 
     states = [dict(carrfreq=r["acqfreq"], codefreq=c.crate, remcode=0.0, remcarr=0.0, buffloc=r["buffloc"])
               for c, r in zip(chans, res)]
-    engine.ring_commit(1, nsamp)
-    engine.ring_commit(2, nsamp)
     engine.trk_set_state(states)
     engine.trk_run(10)                                   # LOOP_MS = 10 epochs, ref src/sdr.h:152
     II, QQ, ns = engine.trk_fetch()

@@ -99,14 +99,15 @@ def test_trk_ring_wrap(gc, orc, engine):
     nsamples = ringlen
     data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[3, 9], nsamples=nsamples,
                                        seed=5, buffloc0=ringlen - 9000, ringlen=ringlen)
-    # pretend the writer lapped the ring twice more: same bytes, write position two rings further
-    engine.ring_commit(1, 2 * ringlen)
+    # pretend the writer went on for another lap and a bit: same bytes, the periods tracked straddle the end
+    # of the ring and lie inside what it holds
+    engine.ring_commit(1, ringlen + 40000)
     for s in states:
         s["buffloc"] += ringlen
     engine.trk_set_state(states)
     engine.trk_run(2)
     II, QQ, ns = engine.trk_fetch()
-    oII, oQQ, ons, _ = _oracle_run(orc, ochs, states, data, ringlen, 3 * ringlen, 2)
+    oII, oQQ, ons, _ = _oracle_run(orc, ochs, states, data, ringlen, 2 * ringlen + 40000, 2)
     assert np.array_equal(ns, ons) and np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
 
 
@@ -330,8 +331,10 @@ def test_closed_loop_from_acquisition_state(gc, orc, engine, synth):
         # code phase of the synthesized signal -> first sample of a code period (what acqcodei gives)
         buffloc = int(round((1023 - cph[i]) * 16)) % 16368
         for e in range(40):
-            engine.trk_set_state([dict(carrfreq=o.carrfreq, codefreq=o.codefreq, remcode=o.remcode,
-                                       remcarr=o.remcarr, buffloc=buffloc)], ch0=i)
+            # (the other channels are parked: a zero chip rate makes their periods empty)
+            sts = [dict(carrfreq=0.0, codefreq=0.0, remcode=0.0, remcarr=0.0, buffloc=0) for _ in chans]
+            sts[i] = dict(carrfreq=o.carrfreq, codefreq=o.codefreq, remcode=o.remcode, remcarr=o.remcarr, buffloc=buffloc)
+            engine.trk_set_state(sts)
             engine.trk_run(1)
             II, QQ, ns = engine.trk_fetch()
             st = engine.trk_get_state()[i]
@@ -348,3 +351,27 @@ def test_closed_loop_from_acquisition_state(gc, orc, engine, synth):
             buffloc += o.currnsamp
         # the loops pulled in: prompt power well above the early/late mean by the end
         assert abs(o.carrfreq - dop[i]) < 150.0
+
+
+def test_batch_outside_the_ring_is_refused(gc, orc, engine):
+    """The reference tracks a period only once it is in the buffer (ref src/sdrtrk.c:26-30) and stops when the
+    buffer overruns (ref src/sdrrcv.c:325-349).  A batch that runs past the write position, or over samples
+    that were overwritten since, is reported by the fetch instead of handing out sums of other samples."""
+    ringlen = 16 * 8192
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[3, 9], nsamples=ringlen, seed=6,
+                                       buffloc0=100)
+    engine.trk_run(7)                       # 7 periods fit 131072 samples
+    engine.trk_fetch()
+    engine.trk_run(3)                       # ... the next three do not
+    with pytest.raises(gc.GnsscorrError, match="outside what the IF ring holds"):
+        engine.trk_fetch()
+    # overwritten: the writer is more than a ring ahead of the period asked for
+    engine.ring_commit(1, 3 * ringlen)
+    engine.trk_set_state(states)
+    engine.trk_run(1)
+    with pytest.raises(gc.GnsscorrError, match="outside what the IF ring holds"):
+        engine.trk_fetch()
+    # a ring shorter than a code period is refused when the channels are set
+    engine.ring_create(1, 2, 8192)
+    with pytest.raises(gc.GnsscorrError, match="shorter than a code period"):
+        engine.set_channels([gc.Channel(3, dtype=2, f_if=0.0)])
