@@ -275,6 +275,11 @@ def main():
         tb = np.zeros(4096 * 12, dtype=np.uint64)
         gc.lib().gnsscorr_debug_trk_trace(ctypes.c_void_p(tb.ctypes.data))
         np.save(os.environ["GNSSCORR_TRACE_OUT"], tb.reshape(4096, 12))
+    if os.environ.get("BENCH_PLAN_STATS"):            # (debug) which planner path served the periods
+        import ctypes
+        ps = np.zeros(8, dtype=np.uint64)
+        gc.lib().gnsscorr_debug_plan_stats(ctypes.c_void_p(ps.ctypes.data), 1)
+        log("planner paths [code spec, cert, walk | carrier spec, cert, walk]:", ps[:6].tolist())
     k_ms, k_n = eng.timing_read("trk_corr")
     p_ms, p_n = eng.timing_read("trk_plan")
     s_ms, s_n = eng.timing_read("trk_finish")
@@ -305,8 +310,10 @@ def main():
                    "epochs_per_step": E * args.inner, "taps": ntap, "loop": "open (frequencies held per launch); see closed_loop",
                    "if_broadcast": "RCCL broadcast of each step's IF chunk" if world > 1 else "none (1 GPU)"},
         "roofline": roof,
-        "kernels_ms_per_launch": {"trk_plan": p_ms / max(p_n, 1), "trk_corr": k_ms / max(k_n, 1),
-                                  "trk_finish": s_ms / max(s_n, 1)},
+        "kernels_ms_per_launch": {"trk_spec": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_spec")),
+                                  "trk_plan": p_ms / max(p_n, 1),
+                                  "trk_expand": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_expand")),
+                                  "trk_corr": k_ms / max(k_n, 1), "trk_finish": s_ms / max(s_n, 1)},
     }
 
     # ---- closed loop (pll/dll on the device), same channels ----------------

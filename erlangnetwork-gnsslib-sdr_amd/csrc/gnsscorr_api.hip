@@ -84,6 +84,7 @@ static void free_channels(gnsscorr_ctx *ctx)
 static void free_trk_buffers(gnsscorr_ctx *ctx)
 {
     for (int i = 0; i < 2; i++) { hipFree(ctx->dplan2[i]); ctx->dplan2[i] = nullptr; }
+    hipFree(ctx->dspec); ctx->dspec = nullptr;
     ctx->ahead_valid = false;
     hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
     hipFree(ctx->dcorrQ); ctx->dcorrQ = nullptr;
@@ -576,6 +577,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     }
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dspec, sizeof(int) * 2 * units * GC_SPEC_ROW));
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));
@@ -622,9 +624,14 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         // behind it lets ev_plan[s] stand for "slot s is free and planned" on the main stream
         if (ctx->stream2 && ctx->fin_pending[s]) GC_HIP(hipStreamWaitEvent(ps, ctx->ev_fin[s], 0));
         {
+            GcTimed t(ctx, "trk_spec", ps);
+            int r2 = gc_launch_trk_spec(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->nch, nepoch, ctx->dspec);
+            if (r2) return r2;
+        }
+        {
             GcTimed t(ctx, "trk_plan", ps);
             int r2 = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
-                                        ctx->dplan2[s], ctx->nch, nepoch);
+                                        ctx->dplan2[s], ctx->nch, nepoch, ctx->dspec);
             if (r2) return r2;
         }
         {

@@ -63,6 +63,7 @@ struct gnsscorr_ctx {
     GcTrkState *dstate2[2] = {nullptr, nullptr};   // ping-pong; cur = index of the committed state
     int state_cur = 0;
     GcTrkPlan *dplan2[2] = {nullptr, nullptr};
+    int *dspec = nullptr;                          // speculated NCO crossings of the batch being planned (planner stream)
     int plan_slot = 0;                             // slot the next trk_run consumes
     bool ahead_valid = false;                      // dplan2[plan_slot] already planned (look-ahead)
     int ahead_nepoch = 0;

@@ -953,6 +953,41 @@ struct GcFillLoop {
     }
 };
 
+// Crossings that come from somewhere else than a certified computation on the period's own start value --
+// the planner's speculation pass computes them for all periods of a batch at once from closed-form period
+// starts (gnsscorr_trk.hip: trk_spec_kernel) -- are CHECKED by the chain instead: with y the first value
+// inside a binade and m the claimed number of equal steps, the claim is right exactly when
+// y + m d < top of the binade <= (y + m d) + s, two comparisons beside the chain's two operations.  A
+// fill whose GcFillVerify is true makes the period steps below run the checking form of their chains; a
+// failed check returns false like any other shape mismatch (caller: the certified fill, then the walkers).
+template <class F> struct GcFillVerify { static constexpr bool value = false; };
+
+#define GC_SPEC_ROW 24              // ints per (channel, period) row: K[0..GC_NB], tag = i0 + 1 (0: nothing speculated)
+struct GcFillSpec {
+    int k[GC_SPEC_ROW];
+    GC_HDM bool operator()(int *K, const GcCertCtx &, int i0, int, double) const
+    {
+        if (k[GC_NB + 1] != i0 + 1) return false;
+#pragma unroll
+        for (int i = 0; i <= GC_NB; i++) K[i] = k[i];
+        return true;
+    }
+};
+template <> struct GcFillVerify<GcFillSpec> { static constexpr bool value = true; };
+
+// the speculation pass's fill: the certified crossings of an approximate start value, written to the row
+struct GcFillRecord {
+    int *row;
+    GC_HDM bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
+    {
+        GcFillLoop base;
+        const bool ok = base(K, c, i0, itop, lim);
+        for (int i = 0; i <= GC_NB; i++) row[i] = (ok && i > i0) ? K[i] : 0;
+        row[GC_NB + 1] = ok ? i0 + 1 : 0;
+        return ok;
+    }
+};
+
 // The climb's chain for a table whose binade ITOP holds the code length: written for a compile-time ITOP
 // so that nothing but one fma and one addition per binade sits on the dependency path (the loop bounds,
 // the table entries and the tie test are constants or scalar work beside it).
@@ -1018,10 +1053,40 @@ GC_HD void gc_code_climb_lean(const GcNcoFast &f, const int *K, int i0, int it, 
     *py = y;
 }
 
+// ... and the checking form (GcFillVerify): the crossings are claims
+template <int ITOP, class Emit>
+GC_HD bool gc_code_climb_check(const GcNcoFast &f, const int *K, int i0, int it, double ci, double dlen, double *py, int jbase, Emit &emit)
+{
+    GC_FP_STRICT
+    double y = *py;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i <= ITOP; i++) {
+        if (i == 0 && i0 != 0) continue;
+        int ks = (i == i0) ? 0 : K[i];
+        const int ke = i == ITOP ? K[GC_NB] : K[i + 1];
+        if (i == it) {
+            if ((gc_d2u(y) & 1) && ke - 1 - ks > 0) {
+                emit(jbase + ks, y, 0.0, 1, 1);
+                y = y + ci;
+                ks += 1;
+            }
+        }
+        const int m = ke - 1 - ks;
+        const double top = i == ITOP ? dlen : gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
+        emit(jbase + ks, y, f.d[i], ke - ks, 1);
+        const double yl = fma((double)m, f.d[i], y);
+        y = yl + ci;
+        ok = ok && m >= 0 && yl < top && y >= top;
+    }
+    *py = y;
+    return ok;
+}
+
 // emit(j0, y0, d, count, w) receives the pieces (as gc_code_walk's emitter does) when the step applies;
 // on a false return the emitter may have seen some pieces already: reset it before the fallback.
 template <int ITOP, class Fill, class Emit>
-GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+GC_HD bool gc_code_period_body(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
 {
     GC_FP_STRICT
     const GcNcoFast &f = P.f;
@@ -1069,7 +1134,11 @@ GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt
     int K[GC_NB + 1];
     if (!fill(K, c, i0, ITOP, dlen)) return false;
     if (K[GC_NB] >= c.n) return false;              // (the period must end in the tail)
-    gc_code_climb_lean<ITOP>(f, K, i0, P.it, ci, &y, j, emit);
+    if (GcFillVerify<Fill>::value) {
+        if (!gc_code_climb_check<ITOP>(f, K, i0, P.it, ci, dlen, &y, j, emit)) return false;
+    } else {
+        gc_code_climb_lean<ITOP>(f, K, i0, P.it, ci, &y, j, emit);
+    }
     j += K[GC_NB];
     if (j >= nt || !(y >= dlen)) return false;
     // ---- second wrap and tail
@@ -1091,6 +1160,31 @@ GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt
     }
     *remcode_out = y - P.smaxci;
     return true;
+}
+
+// (out of line: inlined six times into the closed-loop kernel the step made that kernel hang -- a
+// compiler-sensitive failure; the planner's chain, which is nothing but this step, takes the
+// inline form below)
+template <int ITOP, class Fill, class Emit>
+GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+{
+    return gc_code_period_body<ITOP>(P, remcode, nt, fill, remcode_out, emit);
+}
+
+template <class Fill>
+GC_HD bool gc_code_period_inl(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out)
+{
+    GcNoEmit ne;
+    if (!P.ok) return false;
+    switch (P.itop) {
+    case 7:  return gc_code_period_body<7>(P, remcode, nt, fill, remcode_out, ne);
+    case 8:  return gc_code_period_body<8>(P, remcode, nt, fill, remcode_out, ne);
+    case 9:  return gc_code_period_body<9>(P, remcode, nt, fill, remcode_out, ne);
+    case 10: return gc_code_period_body<10>(P, remcode, nt, fill, remcode_out, ne);
+    case 11: return gc_code_period_body<11>(P, remcode, nt, fill, remcode_out, ne);
+    case 12: return gc_code_period_body<12>(P, remcode, nt, fill, remcode_out, ne);
+    default: return false;
+    }
 }
 
 template <class Fill, class Emit>
@@ -1187,6 +1281,13 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
                 }
                 if (m >= 0) emit(k + kb, x, f.d[i], m + 1);
                 x = fma((double)m, f.d[i], x);
+                if (GcFillVerify<Fill>::value) {
+                    // claims: the samples up to `last` stay inside binade i, and -- unless the period ends
+                    // first -- the next one is at or above its top
+                    const double top = gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
+                    const bool ends = (i + 1 < GC_NB ? K[i + 1] : GC_CERT_FAR) - 1 > c.n - 1;
+                    ok = ok && fabs(x) < top && (ends || fabs(x + s) >= top);
+                }
                 x = x + s;
                 kk = last + 1;
             }
@@ -1207,6 +1308,34 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
 {
     GcNoEmit ne;
     return gc_carrier_period(P, remcarr, n, fill, remcarr_out, ne);
+}
+
+// Closed-form start of period e of a batch whose frequencies are held (what the speculation pass works
+// from; never used for a result).  In real numbers the code phase at sample N is remcode0 + N ci, period e
+// starts at sample N_e = floor((e len - remcode0)/spc), and the carrier phase there is remcarr0 + N_e w
+// brought into (0, DPI] by whole subtractions of DPI when it exceeds DPI (ref src/sdrcmn.c:666-668; a
+// falling phase is never wrapped).  The reference's running sums differ from these by their accumulated
+// rounding (~1e-9 after a thousand periods): enough to find the binade crossings of almost every period,
+// and the chain checks every one of them.
+GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc, double ps, double dlen, int e,
+                         double *remcode_e, double *remcarr_e, int *n_e)
+{
+    GC_FP_STRICT
+    const double de = (double)e;
+    const double N0 = e == 0 ? 0.0 : floor((de * dlen - remcode0) / spc);
+    const double N1 = floor(((de + 1.0) * dlen - remcode0) / spc);
+    const double dn = N1 - N0;
+    *n_e = (dn > 0.0 && dn < 2147483648.0) ? (int)dn : 0;
+    const double p = N0 * ci, pe = fma(N0, ci, -p);             // product and its rounding error
+    *remcode_e = (remcode0 + (p - de * dlen)) + pe;
+    const double w = ps * GC_NCO_DPI * (1.0 / GC_NCO_CDIV);
+    const double q = N0 * w, qe = fma(N0, w, -q);
+    double phi = remcarr0 + q;
+    if (phi > GC_NCO_DPI && phi < 1.0e300) {
+        const double M = ceil(phi / GC_NCO_DPI) - 1.0;
+        phi = fma(-M, GC_NCO_DPI, phi);
+    }
+    *remcarr_e = phi + qe;
 }
 
 #if defined(__HIPCC__)

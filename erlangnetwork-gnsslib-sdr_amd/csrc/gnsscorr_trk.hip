@@ -52,6 +52,47 @@ namespace {
 // running sums cross it (certified against the accumulated rounding, gnsscorr_nco.h); what is left
 // to the sequential chain is one fma and one addition per binade.
 
+// Speculation pass: one lane per (channel, period).  From the batch's start state and closed-form period starts
+// (gc_spec_start) it runs the same period steps as the chain, with the certified crossings of those
+// approximate starts as their fill, and keeps the crossings: GC_SPEC_ROW ints per NCO and period.  The chain
+// below takes them as claims and checks each one (two comparisons beside its two operations per binade),
+// so that what is sequential in a batch no longer includes finding the crossings.
+__global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
+                                                       int *__restrict__ spec_code, int *__restrict__ spec_car,
+                                                       int nch, int nepoch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nch * nepoch) return;
+    const int ch = i / nepoch, e = i - ch * nepoch;
+    const GcChan &c = chan[ch];
+    const GcTrkState s = state_in[ch];
+    int *rc = spec_code + (size_t)i * GC_SPEC_ROW, *rk = spec_car + (size_t)i * GC_SPEC_ROW;
+    rc[GC_NB + 1] = 0;
+    rk[GC_NB + 1] = 0;
+    const double ci = __dmul_rn(c.ti, s.codefreq), spc = __ddiv_rn(s.codefreq, c.f_sf), dlen = (double)c.clen;
+    if (!(ci > 0.0 && ci < dlen && spc > 1e-300 && spc < 1e300)) return;
+    double remcode, remcarr, dummy;
+    int n;
+    gc_spec_start(s.remcode, s.remcarr, ci, spc, gc_carrier_ps(s.carrfreq, c.ti), dlen, e, &remcode, &remcarr, &n);
+    if (!(n > 0 && n <= (1 << 24))) return;
+    {
+        GcCodePlan PC;
+        gc_code_plan_init(PC, ci, c.clen, c.smax);
+        GcFillRecord fr{rc};
+        gc_code_period(PC, remcode, n + 2 * c.smax, fr, &dummy);
+    }
+    {
+        GcCarPlan PK;
+        gc_car_plan_init(PK, gc_carrier_ps(s.carrfreq, c.ti));
+        GcFillRecord fr{rk};
+        gc_carrier_period(PK, remcarr, n, fr, &dummy);
+    }
+}
+
+// which path served the periods of the batches planned so far: [0] code speculated, [1] code certified,
+// [2] code walkers, [3..5] the same for the carrier (tools/debug, tests)
+__device__ unsigned long long gc_plan_stats[8];
+
 // Two wavefronts per channel: wavefront 0 chains the code NCO (and with it the samples per period and the
 // buffer positions), wavefront 1 follows one step behind with the carrier NCO, which needs only the
 // period lengths -- the two chains are independent otherwise and each is latency bound.
@@ -59,7 +100,8 @@ namespace {
 __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict__ chan,
                                                        const GcTrkState *__restrict__ state_in,
                                                        GcTrkState *__restrict__ state_out,
-                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch)
+                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch,
+                                                       const int *__restrict__ spec_code, const int *__restrict__ spec_car, int dbg)
 {
     __shared__ int Ks2[2][GC_NB + 2];
     __shared__ int nsh[GC_PLAN_MAXE];
@@ -95,8 +137,31 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
     const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
     const double smaxci = __dmul_rn((double)c.smax, ci);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
+    // the speculated crossings of the period after the one at hand are fetched a period ahead (the rows
+    // are read through the scalar cache: wave-uniform addresses)
+    const bool spec = spec_code != nullptr && spec_car != nullptr;
+    const int4 *rowc = reinterpret_cast<const int4 *>(spec_code) + (size_t)ch * nepoch * (GC_SPEC_ROW / 4);
+    const int4 *rowk = reinterpret_cast<const int4 *>(spec_car) + (size_t)ch * nepoch * (GC_SPEC_ROW / 4);
+    GcFillSpec nxc, nxk;
+    auto fetch = [&](GcFillSpec &f, const int4 *rows, int e) {
+#pragma unroll
+        for (int q = 0; q < GC_SPEC_ROW / 4; q++) {
+            const int4 v = rows[(size_t)e * (GC_SPEC_ROW / 4) + q];
+            f.k[4 * q] = v.x; f.k[4 * q + 1] = v.y; f.k[4 * q + 2] = v.z; f.k[4 * q + 3] = v.w;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < GC_SPEC_ROW; q++) { nxc.k[q] = 0; nxk.k[q] = 0; }
+    if (spec && do_code) fetch(nxc, rowc, 0);
+    if (spec && do_car) fetch(nxk, rowk, 0);
+    unsigned tally[6] = {0, 0, 0, 0, 0, 0};
     for (int e = 0; e < nepoch; e++) {
         int n;
+        GcFillSpec cuc = nxc, cuk = nxk;
+        if (spec && e + 1 < nepoch) {
+            if (do_code) fetch(nxc, rowc, e + 1);
+            if (do_car) fetch(nxk, rowk, e + 1);
+        }
         if (do_code) {
             const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
             const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
@@ -119,23 +184,34 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
             n = nsh[e];
         }
         const bool walk = n > 0 && n <= (1 << 24);
-        if (do_car) {
+        if (do_car && !(dbg & 2)) {
             if (lane == 0) out[e].phi0 = s.remcarr;
             double rp;
-            if (walk && gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
-                s.remcarr = rp;
+            if (walk && spec && gc_carrier_period(PK, s.remcarr, n, cuk, &rp)) {
+                s.remcarr = rp;     // (speculated crossings, checked)
+                tally[3]++;
+            } else if (walk && gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
+                s.remcarr = rp;     // (crossings certified here, one per lane)
+                tally[4]++;
             } else if (walk) {      // any other shape: the general walkers
+                tally[5]++;
                 const double phis = gc_div_y(__dmul_rn(s.remcarr, GC_NCO_CDIV), GC_NCO_DPI, ydpi);     // ref src/sdrcmn.c:649
                 double xn;
                 if (!plan_carrier_dev(fcar, phis, n, Ks, lane, &xn)) xn = gc_fast_carrier_walk(fcar, phis, n, ne);
                 s.remcarr = gc_fast_prem(fprem, xn);
             }
         }
-        if (do_code) {
+        if (do_code && (dbg & 1)) s.buffloc += (uint64_t)(int64_t)n;
+        if (do_code && !(dbg & 1)) {
             double rc;
-            if (walk && code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
+            if (walk && code_ok && spec && gc_code_period_inl(PC, s.remcode, n + 2 * c.smax, cuc, &rc)) {
                 s.remcode = rc;
+                tally[0]++;
+            } else if (walk && code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
+                s.remcode = rc;
+                tally[1]++;
             } else if (walk && code_ok) {
+                tally[2]++;
                 const double c0 = gc_code_start_fast(s.remcode, smaxci, c.clen);
                 double cend;
                 if (!plan_code_dev(fcode, c0, c.clen, n + 2 * c.smax, Ks, lane, &cend))
@@ -153,6 +229,9 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
             state_out[ch].buffloc = s.buffloc;
         }
         if (do_car) state_out[ch].remcarr = s.remcarr;
+#pragma unroll
+        for (int t = 0; t < 6; t++)
+            if (tally[t]) atomicAdd(&gc_plan_stats[t], (unsigned long long)tally[t]);
     }
 }
 
@@ -1444,6 +1523,16 @@ void trk_pick_nit()
 
 }  // namespace
 
+extern "C" int gnsscorr_debug_plan_stats(unsigned long long *dst, int reset)
+{
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_plan_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gc_plan_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+
 int gc_trk_nseg(int dtype, int max_n)
 {
     trk_pick_nit();
@@ -1454,11 +1543,31 @@ int gc_trk_nseg(int dtype, int max_n)
     return g_trk_algo == 1 ? (rounds + GC_MAXR - 1) / GC_MAXR : rounds;
 }
 
-int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
-                       GcTrkPlan *plan, int nch, int nepoch)
+static bool trk_nospec()
 {
+    static const bool nospec = getenv("GNSSCORR_TRK_NOSPEC") != nullptr;
+    return nospec;
+}
+
+// spec: 2 * nch * nepoch * GC_SPEC_ROW ints of scratch for the speculated crossings
+int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *spec)
+{
+    if (!spec || trk_nospec()) return 0;
+    const int total = nch * nepoch;
+    hipLaunchKernelGGL(trk_spec_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, state_in, spec,
+                       spec + (size_t)nch * nepoch * GC_SPEC_ROW, nch, nepoch);
+    GC_HIP(hipGetLastError());
+    return 0;
+}
+
+// spec: filled by gc_launch_trk_spec for the same state and batch (null: the chain certifies its
+// crossings itself, period by period)
+int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
+                       GcTrkPlan *plan, int nch, int nepoch, int *spec)
+{
+    int *sc = (spec && !trk_nospec()) ? spec : nullptr, *sk = sc ? sc + (size_t)nch * nepoch * GC_SPEC_ROW : nullptr;
     hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan,
-                       nch, nepoch);
+                       nch, nepoch, sc, sk, getenv("GNSSCORR_PLAN_DBG") ? atoi(getenv("GNSSCORR_PLAN_DBG")) : 0);
     GC_HIP(hipGetLastError());
     return 0;
 }

@@ -154,6 +154,64 @@ int nco_period_tables(double ti, double freq, double remcarr, double codefreq, i
     return r;
 }
 
+// The planner's batch: crossings speculated from closed-form period starts (trk_spec_kernel), then the chain
+// that checks them (trk_plan_kernel), with the certified fill and the walkers behind it.  State after every
+// period, and how many periods each path served (hits[0]: speculated code, [1]: speculated carrier,
+// [2]: certified code, [3]: certified carrier, [4]: walkers code, [5]: walkers carrier).
+// shift: added to the speculation's start values (a test's way of making the claims wrong).
+void nco_spec_chain(double ti, double f_sf, double freq, double codefreq, int len, int smax, double remcode0, double remcarr0,
+                    int nepoch, double shift_code, double shift_car, double *rem_out, double *prem_out, int *n_out, int *hits)
+{
+    GC_FP_STRICT
+    const double ci = ti * codefreq, spc = codefreq / f_sf, ps = gc_carrier_ps(freq, ti), dlen = (double)len;
+    GcCodePlan PC;
+    GcCarPlan PK;
+    gc_code_plan_init(PC, ci, len, smax);
+    gc_car_plan_init(PK, ps);
+    GcNcoFast fcode = PC.f, fcar = PK.f;
+    const double smaxci = (double)smax * ci, ydpi = 1.0 / GC_NCO_DPI;
+    GcNoEmit ne;
+    double remcode = remcode0, remcarr = remcarr0;
+    for (int i = 0; i < 6; i++) hits[i] = 0;
+    for (int e = 0; e < nepoch; e++) {
+        // speculation (parallel on the device)
+        GcFillSpec sc, sk;
+        sc.k[GC_NB + 1] = 0;
+        sk.k[GC_NB + 1] = 0;
+        {
+            double rc, rk, dummy;
+            int ns;
+            gc_spec_start(remcode0, remcarr0, ci, spc, ps, dlen, e, &rc, &rk, &ns);
+            if (ns > 0) {
+                GcFillRecord frc{sc.k}, frk{sk.k};
+                gc_code_period(PC, rc + shift_code, ns + 2 * smax, frc, &dummy);
+                gc_carrier_period(PK, rk + shift_car, ns, frk, &dummy);
+            }
+        }
+        // chain
+        const int n = (int)((dlen - remcode) / spc);
+        n_out[e] = n;
+        double r;
+        GcFillLoop fill;
+        if (gc_carrier_period(PK, remcarr, n, sk, &r)) hits[1]++;
+        else if (gc_carrier_period(PK, remcarr, n, fill, &r)) hits[3]++;
+        else {
+            hits[5]++;
+            r = gc_fast_prem(PK.fprem, gc_fast_carrier_walk(fcar, gc_div_y(remcarr * GC_NCO_CDIV, GC_NCO_DPI, ydpi), n, ne));
+        }
+        remcarr = r;
+        if (gc_code_period(PC, remcode, n + 2 * smax, sc, &r)) hits[0]++;
+        else if (gc_code_period(PC, remcode, n + 2 * smax, fill, &r)) hits[2]++;
+        else {
+            hits[4]++;
+            r = gc_fast_code_walk(fcode, gc_code_start_fast(remcode, smaxci, len), len, n + 2 * smax, ne) - smaxci;
+        }
+        remcode = r;
+        rem_out[e] = remcode;
+        prem_out[e] = remcarr;
+    }
+}
+
 // end values only (what the planner chains)
 void nco_chain(double phi0, double freq, double ti, int n, int len, double coff, int smax, double ci,
                double *prem, double *rem)

@@ -31,6 +31,7 @@ def nco(tmp_path_factory):
     L.nco_code_period.argtypes = [d, d, i, d, i, i, C.POINTER(d)]
     L.nco_carrier_period.argtypes = [d, d, d, i, C.POINTER(d)]
     L.nco_period_tables.argtypes = [d, d, d, d, i, d, i, i, vp, vp, C.POINTER(d), C.POINTER(d)]
+    L.nco_spec_chain.argtypes = [d, d, d, d, i, i, d, d, i, d, d, vp, vp, vp, vp]
     L.nco_carrier_fast.argtypes = L.nco_carrier.argtypes
     L.nco_code_fast.argtypes = L.nco_code.argtypes
     return L
@@ -233,6 +234,51 @@ def test_chain_matches_literal_loops_over_many_periods(nco, orc):
         # (the first period starts from code phase exactly 0: its sixth sample lands on the code length to
         # the last bit -- not certifiable either)
         assert ncert.get(3, 0) + ncert.get(2, 0) >= 299, ncert
+
+
+def _literal_chain(orc, carrfreq, codefreq, remcode, remcarr, nper, smax=6, length=1023):
+    L = orc.lib()
+    ti = 1 / F_SF
+    code = np.arange(length, dtype=np.int16)
+    rems, prems, ns = [], [], []
+    for _ in range(nper):
+        n = int((length - remcode) / (codefreq / F_SF))
+        data = np.ones(n, np.int8)
+        I, Q = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        rc = np.zeros(n + 2 * smax, np.int16)
+        remcarr = L.orc_mixcarr_seq(data.ctypes.data, 1, ti, n, carrfreq, remcarr, I.ctypes.data, Q.ctypes.data)
+        remcode = L.orc_rescode_seq(code.ctypes.data, length, remcode, smax, ti * codefreq, n, rc.ctypes.data)
+        rems.append(remcode)
+        prems.append(remcarr)
+        ns.append(n)
+    return np.array(rems), np.array(prems), np.array(ns)
+
+
+@pytest.mark.parametrize("shift_code,shift_car", [(0.0, 0.0), (0.03, 0.005), (-3e-9, 2e-9)])
+def test_speculated_crossings_are_checked_by_the_chain(nco, orc, shift_code, shift_car):
+    """The planner's batch form (trk_spec_kernel + trk_plan_kernel): binade crossings speculated for all
+    periods at once from closed-form period starts, checked by the sequential chain.  Every chained value
+    equals the literal loops' -- also when the speculation is fed start values that are off by half a
+    sample (its claims are then wrong and the chain must notice) -- and with honest start values the
+    speculated path is the one that serves nearly every period."""
+    ti = 1 / F_SF
+    nper = 250
+    cases = [(2200.3, 1.023e6 + 1.4, 0.31, 1.7), (-1400.7, 1.023e6 - 2.7, 511.2, 0.0), (137.77, 1.023e6 + 2.9, 0.0, 6.1),
+             (4999.1, 1.023e6 - 0.01, 1022.4, 3.3), (-4876.2, 1.023e6 + 3.1, 17.0, -40.0), (0.0, 1.023e6, 0.0, 0.0)]
+    for carrfreq, codefreq, remcode0, remcarr0 in cases:
+        orem, oprem, on = _literal_chain(orc, carrfreq, codefreq, remcode0, remcarr0, nper)
+        rem, prem = np.zeros(nper), np.zeros(nper)
+        n, hits = np.zeros(nper, np.int32), np.zeros(6, np.int32)
+        nco.nco_spec_chain(ti, F_SF, carrfreq, codefreq, 1023, 6, remcode0, remcarr0, nper, shift_code, shift_car,
+                           rem.ctypes.data, prem.ctypes.data, n.ctypes.data, hits.ctypes.data)
+        assert np.array_equal(n, on), (carrfreq, codefreq)
+        assert np.array_equal(rem, orem), (carrfreq, codefreq, hits)
+        assert np.array_equal(prem, oprem), (carrfreq, codefreq, hits)
+        if shift_code == 0.0 and carrfreq != 0.0 and codefreq != 1.023e6:
+            assert hits[0] >= nper - 5 and hits[1] >= nper - 5, (carrfreq, codefreq, hits)
+        # (shifted start values: whatever claims still pass are right -- the code's boundaries are multiples of
+        # the nominal chip step 1/16, so its crossings hardly depend on the start value; the values above
+        # are what counts)
 
 
 def test_certified_chain_random_states(nco, orc):
