@@ -280,6 +280,12 @@ def main():
         ps = np.zeros(8, dtype=np.uint64)
         gc.lib().gnsscorr_debug_plan_stats(ctypes.c_void_p(ps.ctypes.data), 1)
         log("planner paths [code spec, cert, walk | carrier spec, cert, walk]:", ps[:6].tolist())
+        if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):
+            pp = np.zeros(16, dtype=np.uint64)
+            gc.lib().gnsscorr_debug_plan_prof(ctypes.c_void_p(pp.ctypes.data))
+            nper = E * args.inner * (args.steps + args.warmup) + E
+            log("planner clocks/period, channel 0: code [rows+n, step, rest, block] carrier [wait, rows, -, step]:",
+                [round(float(v) / nper, 1) for v in pp[:8]])
     k_ms, k_n = eng.timing_read("trk_corr")
     p_ms, p_n = eng.timing_read("trk_plan")
     s_ms, s_n = eng.timing_read("trk_finish")

@@ -577,7 +577,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     }
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
-    GC_HIP(hipMalloc((void **)&ctx->dspec, sizeof(int) * 2 * units * GC_SPEC_ROW));
+    GC_HIP(hipMalloc((void **)&ctx->dspec, sizeof(int) * 2 * units * GC_CLAIM_ROW));
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));

@@ -131,7 +131,7 @@ struct GcRound {
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
 int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *spec);
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
-                       GcTrkPlan *plan, int nch, int nepoch, int *spec);
+                       GcTrkPlan *plan, int nch, int nepoch, int *claims);
 // nco_overflow: device counter of units whose NCO tables did not fit (their outputs are zero)
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit, GcUnitSegs *segs,
                          int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n, int *nco_overflow);

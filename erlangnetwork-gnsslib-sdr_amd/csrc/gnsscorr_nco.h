@@ -397,7 +397,14 @@ GC_HD void gc_fast_init(GcNcoFast &f, double s, bool with_inv = true)
 
 // one table piece: x in binade ex0 + i, growing.  lim_below: values must stay below it (code: the code
 // length; carrier: +inf).  Returns the run length m <= cap with x + j d exact for j <= m.
+GC_HD int gc_piece_len(double d, double inv, double x, int cap, double lim_below);
 GC_HD int gc_fast_piece(const GcNcoFast &f, int i, double x, int cap, double lim_below)
+{
+    return gc_piece_len(f.d[i], f.inv[i], x, cap, lim_below);
+}
+
+// d, inv: the step RN_u(s) of x's binade and RN(1/|d|)
+GC_HD int gc_piece_len(double d, double inv, double x, int cap, double lim_below)
 {
     GC_FP_STRICT
     // (written without branches: on the device this runs on one lane of a wavefront, where a taken
@@ -407,8 +414,8 @@ GC_HD int gc_fast_piece(const GcNcoFast &f, int i, double x, int cap, double lim
     const double u = gc_u2d((uint64_t)(((ux >> 52) & 0x7FF) - 52) << 52);   // its grid
     const double lim = lim_below <= top ? lim_below - u : top;              // below lim_below, on the grid
     const double R = lim - fabs(x);                                         // exact (same binade)
-    const double dabs = fabs(f.d[i]);
-    double q = floor(R * f.inv[i]);
+    const double dabs = fabs(d);
+    double q = floor(R * inv);
     const double r = fma(-q, dabs, R);                                      // exact
     q += r < 0.0 ? -1.0 : (r >= dabs ? 1.0 : 0.0);
     q = q < 0.0 ? 0.0 : q;
@@ -953,41 +960,6 @@ struct GcFillLoop {
     }
 };
 
-// Crossings that come from somewhere else than a certified computation on the period's own start value --
-// the planner's speculation pass computes them for all periods of a batch at once from closed-form period
-// starts (gnsscorr_trk.hip: trk_spec_kernel) -- are CHECKED by the chain instead: with y the first value
-// inside a binade and m the claimed number of equal steps, the claim is right exactly when
-// y + m d < top of the binade <= (y + m d) + s, two comparisons beside the chain's two operations.  A
-// fill whose GcFillVerify is true makes the period steps below run the checking form of their chains; a
-// failed check returns false like any other shape mismatch (caller: the certified fill, then the walkers).
-template <class F> struct GcFillVerify { static constexpr bool value = false; };
-
-#define GC_SPEC_ROW 24              // ints per (channel, period) row: K[0..GC_NB], tag = i0 + 1 (0: nothing speculated)
-struct GcFillSpec {
-    int k[GC_SPEC_ROW];
-    GC_HDM bool operator()(int *K, const GcCertCtx &, int i0, int, double) const
-    {
-        if (k[GC_NB + 1] != i0 + 1) return false;
-#pragma unroll
-        for (int i = 0; i <= GC_NB; i++) K[i] = k[i];
-        return true;
-    }
-};
-template <> struct GcFillVerify<GcFillSpec> { static constexpr bool value = true; };
-
-// the speculation pass's fill: the certified crossings of an approximate start value, written to the row
-struct GcFillRecord {
-    int *row;
-    GC_HDM bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const
-    {
-        GcFillLoop base;
-        const bool ok = base(K, c, i0, itop, lim);
-        for (int i = 0; i <= GC_NB; i++) row[i] = (ok && i > i0) ? K[i] : 0;
-        row[GC_NB + 1] = ok ? i0 + 1 : 0;
-        return ok;
-    }
-};
-
 // The climb's chain for a table whose binade ITOP holds the code length: written for a compile-time ITOP
 // so that nothing but one fma and one addition per binade sits on the dependency path (the loop bounds,
 // the table entries and the tie test are constants or scalar work beside it).
@@ -1053,36 +1025,6 @@ GC_HD void gc_code_climb_lean(const GcNcoFast &f, const int *K, int i0, int it, 
     *py = y;
 }
 
-// ... and the checking form (GcFillVerify): the crossings are claims
-template <int ITOP, class Emit>
-GC_HD bool gc_code_climb_check(const GcNcoFast &f, const int *K, int i0, int it, double ci, double dlen, double *py, int jbase, Emit &emit)
-{
-    GC_FP_STRICT
-    double y = *py;
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i <= ITOP; i++) {
-        if (i == 0 && i0 != 0) continue;
-        int ks = (i == i0) ? 0 : K[i];
-        const int ke = i == ITOP ? K[GC_NB] : K[i + 1];
-        if (i == it) {
-            if ((gc_d2u(y) & 1) && ke - 1 - ks > 0) {
-                emit(jbase + ks, y, 0.0, 1, 1);
-                y = y + ci;
-                ks += 1;
-            }
-        }
-        const int m = ke - 1 - ks;
-        const double top = i == ITOP ? dlen : gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
-        emit(jbase + ks, y, f.d[i], ke - ks, 1);
-        const double yl = fma((double)m, f.d[i], y);
-        y = yl + ci;
-        ok = ok && m >= 0 && yl < top && y >= top;
-    }
-    *py = y;
-    return ok;
-}
-
 // emit(j0, y0, d, count, w) receives the pieces (as gc_code_walk's emitter does) when the step applies;
 // on a false return the emitter may have seen some pieces already: reset it before the fallback.
 template <int ITOP, class Fill, class Emit>
@@ -1134,11 +1076,7 @@ GC_HD bool gc_code_period_body(const GcCodePlan &P, double remcode, int nt, Fill
     int K[GC_NB + 1];
     if (!fill(K, c, i0, ITOP, dlen)) return false;
     if (K[GC_NB] >= c.n) return false;              // (the period must end in the tail)
-    if (GcFillVerify<Fill>::value) {
-        if (!gc_code_climb_check<ITOP>(f, K, i0, P.it, ci, dlen, &y, j, emit)) return false;
-    } else {
-        gc_code_climb_lean<ITOP>(f, K, i0, P.it, ci, &y, j, emit);
-    }
+    gc_code_climb_lean<ITOP>(f, K, i0, P.it, ci, &y, j, emit);
     j += K[GC_NB];
     if (j >= nt || !(y >= dlen)) return false;
     // ---- second wrap and tail
@@ -1163,28 +1101,11 @@ GC_HD bool gc_code_period_body(const GcCodePlan &P, double remcode, int nt, Fill
 }
 
 // (out of line: inlined six times into the closed-loop kernel the step made that kernel hang -- a
-// compiler-sensitive failure; the planner's chain, which is nothing but this step, takes the
-// inline form below)
+// compiler-sensitive failure)
 template <int ITOP, class Fill, class Emit>
 GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
 {
     return gc_code_period_body<ITOP>(P, remcode, nt, fill, remcode_out, emit);
-}
-
-template <class Fill>
-GC_HD bool gc_code_period_inl(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out)
-{
-    GcNoEmit ne;
-    if (!P.ok) return false;
-    switch (P.itop) {
-    case 7:  return gc_code_period_body<7>(P, remcode, nt, fill, remcode_out, ne);
-    case 8:  return gc_code_period_body<8>(P, remcode, nt, fill, remcode_out, ne);
-    case 9:  return gc_code_period_body<9>(P, remcode, nt, fill, remcode_out, ne);
-    case 10: return gc_code_period_body<10>(P, remcode, nt, fill, remcode_out, ne);
-    case 11: return gc_code_period_body<11>(P, remcode, nt, fill, remcode_out, ne);
-    case 12: return gc_code_period_body<12>(P, remcode, nt, fill, remcode_out, ne);
-    default: return false;
-    }
 }
 
 template <class Fill, class Emit>
@@ -1281,13 +1202,6 @@ GC_HD bool gc_carrier_period(const GcCarPlan &P, double remcarr, int n, Fill &fi
                 }
                 if (m >= 0) emit(k + kb, x, f.d[i], m + 1);
                 x = fma((double)m, f.d[i], x);
-                if (GcFillVerify<Fill>::value) {
-                    // claims: the samples up to `last` stay inside binade i, and -- unless the period ends
-                    // first -- the next one is at or above its top
-                    const double top = gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
-                    const bool ends = (i + 1 < GC_NB ? K[i + 1] : GC_CERT_FAR) - 1 > c.n - 1;
-                    ok = ok && fabs(x) < top && (ends || fabs(x + s) >= top);
-                }
                 x = x + s;
                 kk = last + 1;
             }
@@ -1336,6 +1250,345 @@ GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc
         phi = fma(-M, GC_NCO_DPI, phi);
     }
     *remcarr_e = phi + qe;
+}
+
+// ---------------------------------------------------------------------------
+// period steps on claims: the planner's batch form
+// ---------------------------------------------------------------------------
+// On the device the chain of a channel runs on one wavefront and pays a few clocks per INSTRUCTION whatever
+// it does (and ~25 per taken branch), so the batch planner splits a period step in two:
+//
+//   discover  (one lane per period, all periods of a batch side by side: trk_spec_kernel) works from the
+//             closed-form period start (gc_spec_start) and finds the STRUCTURE of the step: how many equal
+//             steps the head takes, how many of the reference's own additions follow next to zero, how many
+//             equal steps each binade takes, how many subtractions the phase remainder needs -- integers,
+//             the "claims" of the period;
+//   evaluate  (the sequential chain: trk_plan2_kernel) runs the step from the exact period start as one
+//             fixed, branch-free sequence of positions -- literal additions whose addend is the step or
+//             zero, binade segments y -> fma(dm, d, y + pre) + step -- with the claims as its data, and
+//             checks every claim against the values it produces: a segment's last value below the top of
+//             its binade and its successor at or above, a literal addition only below the table, the
+//             period's samples adding up.  The checks are the definitions of the claimed numbers, so a
+//             step that passes them has produced the reference's values; one that fails them (the
+//             closed-form start was a rounding away from the truth: a few periods in ten thousand) returns
+//             false and the caller takes the certified step above, then the walkers.
+//
+// Both are the same function (template parameter DISCOVER), so there is one statement of the step's shape.
+// In the binade where the addend is a tie (at most one) the segment always starts with one of the
+// reference's own additions (pre): from an odd multiplier that step rounds to the even neighbour, from an
+// even one it equals the table's step -- either way the rest of the segment starts even, where the table's
+// step holds.
+#define GC_CLAIM_ROW   20           // ints per (channel, period) row of either NCO
+#define GC_CLAIM_LIT   5            // code: literal additions after the first wrap, at most (as gc_code_period_body)
+#define GC_CLAIM_TAIL  16           // code: literal additions after the second wrap, at most
+#define GC_CLAIM_CLIT  8            // carrier: literal additions next to zero, at most (as gc_carrier_period)
+#define GC_CLAIM_CSEG  13           // carrier: binade segments, at most
+#define GC_CLAIM_PREM  12           // carrier: subtractions of DPI in the remainder loop, at most (12: up to ~11 kHz at 1 ms)
+
+struct GcCodeClaims {               // GC_CLAIM_ROW ints
+    int tag;                        // 1: claims present
+    int i0, q, nl, jsum;            // entry binade of the climb, head steps, literal additions, samples before the tail
+    int dm[13];                     // equal steps per table binade 0..ITOP (after the tie binade's own addition)
+    int pad[2];
+};
+
+struct GcCarClaims {                // GC_CLAIM_ROW ints
+    int tag;                        // 1: table walk, 2: one binade far above the table (no claims needed)
+    int nl, i0, nseg, kprem;        // literal additions, entry binade, binade segments, subtractions of DPI
+    int dm[GC_CLAIM_CSEG];
+    int pad[2];
+};
+
+GC_HD int gc_expo(double x) { return (int)((gc_d2u(x) >> 52) & 0x7FF); }
+
+// per-channel constants of the code step, as the evaluation wants them: every one a plain value (on the device
+// they are pinned to vector registers, GC_PIN_V: the chain's wavefront has few scalar registers to spare)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_PIN_V(x) asm volatile("" : "+v"(x))
+#else
+#define GC_PIN_V(x) do { } while (0)
+#endif
+template <int ITOP>
+struct GcCodeStepC {
+    double d[ITOP + 1], top[ITOP + 1], pre[ITOP + 1];      // step, top of the binade (the code length for ITOP), the tie binade's own addition (ci or 0)
+    double ci, dlen, b0, smaxci;
+    int    ex_top;                                          // biased exponent the start value must have
+};
+
+template <int ITOP>
+GC_HD void gc_code_stepc_init(GcCodeStepC<ITOP> &C, const GcCodePlan &P)
+{
+    C.ci = P.f.s;
+    C.dlen = P.dlen;
+    C.b0 = gc_u2d((uint64_t)P.f.ex0 << 52);
+    C.smaxci = P.smaxci;
+    C.ex_top = P.f.ex0 + ITOP;
+#pragma unroll
+    for (int i = 0; i <= ITOP; i++) {
+        C.d[i] = P.f.d[i];
+        C.top[i] = i == ITOP ? P.dlen : gc_u2d((uint64_t)(P.f.ex0 + i + 1) << 52);
+        C.pre[i] = i == P.it ? P.f.s : 0.0;
+        GC_PIN_V(C.d[i]);
+        GC_PIN_V(C.top[i]);
+        GC_PIN_V(C.pre[i]);
+    }
+    GC_PIN_V(C.ci);
+    GC_PIN_V(C.dlen);
+    GC_PIN_V(C.b0);
+    GC_PIN_V(C.smaxci);
+}
+
+template <int ITOP, int TMAX, bool DISCOVER>
+GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, double remcode, int nt, GcCodeClaims &cl,
+                               double *remcode_out)
+{
+    GC_FP_STRICT
+    const double ci = C.ci, dlen = C.dlen, dtop = C.d[ITOP];
+    bool ok = DISCOVER || cl.tag == 1;
+    // ---- start value (ref src/sdrcmn.c:613-614) and head, as gc_code_period_body
+    const double cs = remcode - C.smaxci;
+    const double c0 = cs < 0.0 ? cs + dlen : cs;
+    ok = ok && cs >= -dlen && cs < dlen && gc_expo(c0) == C.ex_top && c0 < dlen;
+    int q;
+    if (DISCOVER) {
+        const double R = P.limtop - c0;
+        double qd = floor(R * P.f.inv[ITOP]);
+        const double r = fma(-qd, dtop, R);
+        qd += r < 0.0 ? -1.0 : (r >= dtop ? 1.0 : 0.0);
+        q = (qd >= 0.0 && qd < 1.0e9) ? (int)qd : -1;
+        cl.q = q;
+    } else {
+        q = cl.q;
+    }
+    const double dq = (double)q;
+    const double yq = fma(dq, dtop, c0);            // last sample below the code length ...
+    double y = fma(dq + 1.0, dtop, c0);             // ... and the first at or above it
+    ok = ok && q >= 0 && q < nt - 2 && yq < dlen && y >= dlen;
+    y = y - dlen;
+    // ---- next to zero: the reference's own additions up to the table
+    const double b0 = C.b0;
+    int nl;
+    if (DISCOVER) {
+        nl = 0;
+        double t = y;
+        for (int k = 0; k < GC_CLAIM_LIT; k++)
+            if (t < b0) { t = t + ci; nl++; }
+        cl.nl = nl;
+    } else {
+        nl = cl.nl;
+    }
+#pragma unroll
+    for (int k = 0; k < GC_CLAIM_LIT; k++) {
+        const bool lit = k < nl;
+        ok = ok && (!lit || y < b0);
+        y = y + (lit ? ci : 0.0);
+    }
+    ok = ok && y >= b0 && nl >= 0 && q + 1 + nl < nt - 2;
+    const int i0 = gc_expo(y) - (C.ex_top - ITOP);
+    if (DISCOVER) cl.i0 = i0;
+    ok = ok && i0 == cl.i0 && i0 >= 0 && i0 <= 1;
+    // ---- climb: one segment per table binade (only binade 0 can be skipped: i0 is 0 or 1)
+    int j = q + 1 + nl;
+#pragma unroll
+    for (int i = 0; i <= ITOP; i++) {
+        const bool active = i > 0 || i0 == 0;
+        const double y1 = y + (active ? C.pre[i] : 0.0);
+        int dm;
+        if (DISCOVER) {
+            dm = active ? gc_fast_piece(P.f, i, y1, 1 << 24, i == ITOP ? dlen : INFINITY) : 0;
+            cl.dm[i] = dm;
+            j += active ? (C.pre[i] != 0.0 ? 1 : 0) + dm + 1 : 0;
+        } else {
+            dm = cl.dm[i];
+        }
+        const double yl = fma((double)dm, C.d[i], y1);
+        const double yn = yl + ci;
+        ok = ok && (!active || (dm >= 0 && yl < C.top[i] && yn >= C.top[i]));
+        y = active ? yn : y;
+    }
+    if (DISCOVER) {
+#pragma unroll
+        for (int i = ITOP + 1; i < 13; i++) cl.dm[i] = 0;
+        cl.jsum = j;
+        cl.pad[0] = cl.pad[1] = 0;
+    } else {
+        j = cl.jsum;                                // (the sum the discovering run of this function formed of the same claims)
+    }
+    // ---- second wrap and tail
+    y = y - dlen;
+    const int t = nt - j;
+    ok = ok && t >= 1 && t <= TMAX;
+#pragma unroll
+    for (int k = 0; k < TMAX; k++) y = y + (k < t ? ci : 0.0);
+    *remcode_out = y - C.smaxci;
+    if (DISCOVER) cl.tag = ok ? 1 : 0;
+    return ok;
+}
+
+template <int ITOP, bool DISCOVER>
+GC_HD bool gc_code_claims_itop(const GcCodePlan &P, double remcode, int nt, GcCodeClaims &cl, double *remcode_out)
+{
+    GcCodeStepC<ITOP> C;
+    gc_code_stepc_init(C, P);
+    return gc_code_claims_step<ITOP, GC_CLAIM_TAIL, DISCOVER>(P, C, remcode, nt, cl, remcode_out);
+}
+
+template <bool DISCOVER>
+GC_HD bool gc_code_claims(const GcCodePlan &P, double remcode, int nt, GcCodeClaims &cl, double *remcode_out)
+{
+    if (DISCOVER) cl.tag = 0;
+    if (!P.ok) return false;
+    switch (P.itop) {           // (GPS / GLONASS codes at 2..64 samples per chip: 7..12)
+    case 7:  return gc_code_claims_itop<7, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    case 8:  return gc_code_claims_itop<8, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    case 9:  return gc_code_claims_itop<9, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    case 10: return gc_code_claims_itop<10, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    case 11: return gc_code_claims_itop<11, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    case 12: return gc_code_claims_itop<12, DISCOVER>(P, remcode, nt, cl, remcode_out);
+    default: return false;
+    }
+}
+
+// Carrier step on claims.  A tracked channel's phase (in LUT steps) starts a period inside (0, 32] -- or, for a
+// falling phase, which is never wrapped, anywhere below zero -- and climbs a few binades in magnitude.  Two
+// shapes are evaluated:
+//   window      the period starts and ends inside the GC_CLAIM_CWIN table binades that hold the largest phase a
+//               rising period of this channel can reach (per channel: GcCarStepC.ilo): one position per binade,
+//               constants in registers;
+//   one binade  the whole period inside one binade, whichever (gc_one_binade_walk: the usual case for a phase
+//               far from zero).
+// Anything else -- a start next to zero, a start below the window -- is left to the certified step and the
+// walkers.
+#define GC_CLAIM_CWIN 8
+struct GcCarStepC {
+    double d[GC_CLAIM_CWIN], top[GC_CLAIM_CWIN], pre[GC_CLAIM_CWIN];   // step, top of the binade, the tie binade's own addition (s or 0)
+    double s;
+    int    ilo, ex0;                // first binade of the window; biased exponent of table binade 0
+};
+
+// nmax: the longest period the channel is expected to have (samples); a longer one only loses the fast path
+GC_HD void gc_car_stepc_init(GcCarStepC &C, const GcCarPlan &P, int nmax)
+{
+    GC_FP_STRICT
+    const GcNcoFast &f = P.f;
+    C.s = f.s;
+    C.ex0 = f.ex0;
+    C.ilo = 0;
+    if (f.ex0 != 0x7FFFFFF) {
+        const double xmax = fma((double)nmax, fabs(f.s), GC_NCO_CDIV);
+        int imax = gc_expo(xmax) - f.ex0;
+        imax = imax < GC_CLAIM_CWIN - 1 ? GC_CLAIM_CWIN - 1 : (imax > GC_NB - 1 ? GC_NB - 1 : imax);
+        C.ilo = imax - (GC_CLAIM_CWIN - 1);
+    }
+#pragma unroll
+    for (int p = 0; p < GC_CLAIM_CWIN; p++) {
+        C.d[p] = 0.0;
+        C.top[p] = 0.0;
+        C.pre[p] = 0.0;
+#pragma unroll
+        for (int i = 0; i < GC_NB; i++) {           // (static indices into the table)
+            if (i != C.ilo + p) continue;
+            C.d[p] = f.d[i];
+            C.top[p] = gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
+            C.pre[p] = ((f.tie >> i) & 1) ? f.s : 0.0;
+        }
+        GC_PIN_V(C.d[p]);
+        GC_PIN_V(C.top[p]);
+        GC_PIN_V(C.pre[p]);
+    }
+    GC_PIN_V(C.s);
+}
+
+template <bool DISCOVER>
+GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, double remcarr, int n, GcCarClaims &cl, double *remcarr_out)
+{
+    GC_FP_STRICT
+    const double s = C.s;
+    if (DISCOVER) {
+        cl.tag = 0;
+        cl.nl = cl.i0 = cl.nseg = cl.kprem = 0;
+        for (int j = 0; j < GC_CLAIM_CSEG; j++) cl.dm[j] = 0;
+        cl.pad[0] = cl.pad[1] = 0;
+    }
+    if (C.ex0 == 0x7FFFFFF || n < 1) return false;
+    double x = gc_div_y(remcarr * GC_NCO_CDIV, GC_NCO_DPI, P.ydpi);      // ref src/sdrcmn.c:649
+    bool ok = true;
+    if (DISCOVER) {
+        double xe;
+        cl.tag = gc_one_binade_walk(x, s, n, &xe) ? 2 : 1;
+    }
+    if (cl.tag == 2) {
+        if (!gc_one_binade_walk(x, s, n, &x)) { if (DISCOVER) cl.tag = 0; return false; }
+    } else {
+        ok = cl.tag == 1;
+        const int i0 = gc_expo(x) - C.ex0, p0 = i0 - C.ilo;
+        ok = ok & (p0 >= 0) & (p0 < GC_CLAIM_CWIN) & ((gc_d2u(x) >> 63) == (gc_d2u(s) >> 63)) & (x != 0.0);
+        if (DISCOVER) {
+            // the segments, as gc_fast_carrier_walk steps them; dm by window position
+            cl.i0 = i0;
+            int k = 0, nseg = 0;
+            double t = x;
+            bool fits = ok;
+            for (int p = 0; p < GC_CLAIM_CWIN; p++) {
+                if (!fits || p < p0 || k >= n) continue;
+                if (gc_expo(t) != C.ex0 + C.ilo + p) { fits = false; continue; }
+                if (C.pre[p] != 0.0) {
+                    if (k >= n - 1) { fits = false; continue; }     // (the tie binade's addition would be the period's last: not here)
+                    t = t + s;
+                    k += 1;
+                    if (gc_expo(t) != C.ex0 + C.ilo + p) { fits = false; continue; }
+                }
+                const int m = gc_piece_len(C.d[p], 1.0 / fabs(C.d[p]), t, n - 1 - k, INFINITY);
+                cl.dm[p] = m;
+                t = fma((double)m, C.d[p], t);
+                k += m;
+                t = t + s;
+                k += 1;
+                nseg++;
+            }
+            if (!fits || k != n) ok = false;
+            cl.nseg = nseg;
+            cl.nl = k;                              // samples the claimed segments add up to
+        }
+        ok = ok & (i0 == cl.i0) & (cl.nseg >= 1) & (p0 + cl.nseg <= GC_CLAIM_CWIN) & (cl.nl == n);
+        const int plast = p0 + cl.nseg - 1;
+#pragma unroll
+        for (int p = 0; p < GC_CLAIM_CWIN; p++) {
+            const bool active = (p >= p0) & (p <= plast), last = p == plast;
+            const int dm = cl.dm[p];
+            const double x1 = x + C.pre[p];
+            const double xl = fma((double)dm, C.d[p], x1);
+            const double xn = xl + s;
+            ok = ok & ((int)!active | ((int)(dm >= 0) & (int)(fabs(xl) < C.top[p]) & ((int)last | (int)(fabs(xn) >= C.top[p]))));
+            x = active ? xn : x;
+        }
+    }
+    // ---- phase remainder (ref :666-668): the reference's own subtractions, the last one in the last position
+    double p = x * GC_NCO_DPI * (1.0 / GC_NCO_CDIV);
+    ok = ok & (p < 1.0e300);
+    int kp;
+    if (DISCOVER) {
+        kp = 0;
+        double t = p;
+        for (int k = 0; k < GC_CLAIM_PREM; k++)
+            if (t > GC_NCO_DPI) { t = t - GC_NCO_DPI; kp++; }
+        cl.kprem = kp;
+    } else {
+        kp = cl.kprem;
+    }
+    ok = ok & (kp >= 0) & (kp <= GC_CLAIM_PREM);
+    double pprev = p;
+#pragma unroll
+    for (int k = 0; k < GC_CLAIM_PREM; k++) {
+        const bool sub = k >= GC_CLAIM_PREM - kp;
+        pprev = p;
+        p = p - (sub ? GC_NCO_DPI : 0.0);
+    }
+    // (the values fall: if the last subtraction was called for, so were the ones before it)
+    ok = ok & ((kp == 0) | (pprev > GC_NCO_DPI)) & !(p > GC_NCO_DPI);
+    *remcarr_out = p;
+    if (DISCOVER && !ok) cl.tag = 0;
+    return ok;
 }
 
 #if defined(__HIPCC__)

@@ -52,13 +52,12 @@ namespace {
 // running sums cross it (certified against the accumulated rounding, gnsscorr_nco.h); what is left
 // to the sequential chain is one fma and one addition per binade.
 
-// Speculation pass: one lane per (channel, period).  From the batch's start state and closed-form period starts
-// (gc_spec_start) it runs the same period steps as the chain, with the certified crossings of those
-// approximate starts as their fill, and keeps the crossings: GC_SPEC_ROW ints per NCO and period.  The chain
-// below takes them as claims and checks each one (two comparisons beside its two operations per binade),
-// so that what is sequential in a batch no longer includes finding the crossings.
+// Discovery pass of the batch planner: one lane per (channel, period).  From the batch's start state and the
+// closed-form period starts (gc_spec_start) it runs the period steps in their discovering form
+// (gnsscorr_nco.h: "period steps on claims") and keeps the structure they find: GC_CLAIM_ROW ints per NCO
+// and period.  What is sequential in a batch -- trk_plan2_kernel -- then only evaluates and checks.
 __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
-                                                       int *__restrict__ spec_code, int *__restrict__ spec_car,
+                                                       int *__restrict__ claims_code, int *__restrict__ claims_car,
                                                        int nch, int nepoch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,32 +65,58 @@ __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__
     const int ch = i / nepoch, e = i - ch * nepoch;
     const GcChan &c = chan[ch];
     const GcTrkState s = state_in[ch];
-    int *rc = spec_code + (size_t)i * GC_SPEC_ROW, *rk = spec_car + (size_t)i * GC_SPEC_ROW;
-    rc[GC_NB + 1] = 0;
-    rk[GC_NB + 1] = 0;
+    GcCodeClaims cc;
+    GcCarClaims ck;
+    cc.tag = 0;
+    ck.tag = 0;
     const double ci = __dmul_rn(c.ti, s.codefreq), spc = __ddiv_rn(s.codefreq, c.f_sf), dlen = (double)c.clen;
-    if (!(ci > 0.0 && ci < dlen && spc > 1e-300 && spc < 1e300)) return;
-    double remcode, remcarr, dummy;
-    int n;
-    gc_spec_start(s.remcode, s.remcarr, ci, spc, gc_carrier_ps(s.carrfreq, c.ti), dlen, e, &remcode, &remcarr, &n);
-    if (!(n > 0 && n <= (1 << 24))) return;
-    {
-        GcCodePlan PC;
-        gc_code_plan_init(PC, ci, c.clen, c.smax);
-        GcFillRecord fr{rc};
-        gc_code_period(PC, remcode, n + 2 * c.smax, fr, &dummy);
+    if (ci > 0.0 && ci < dlen && spc > 1e-300 && spc < 1e300) {
+        double remcode, remcarr, dummy;
+        int n;
+        const double ps = gc_carrier_ps(s.carrfreq, c.ti);
+        gc_spec_start(s.remcode, s.remcarr, ci, spc, ps, dlen, e, &remcode, &remcarr, &n);
+        if (n > 0 && n <= (1 << 24)) {
+            {
+                GcCodePlan PC;
+                gc_code_plan_init(PC, ci, c.clen, c.smax);
+                gc_code_claims<true>(PC, remcode, n + 2 * c.smax, cc, &dummy);
+            }
+            {
+                GcCarPlan PK;
+                gc_car_plan_init(PK, ps, false, false);
+                GcCarStepC CK;
+                gc_car_stepc_init(CK, PK, c.nsamp + 16);
+                gc_carrier_claims_step<true>(PK, CK, remcarr, n, ck, &dummy);
+            }
+        }
     }
-    {
-        GcCarPlan PK;
-        gc_car_plan_init(PK, gc_carrier_ps(s.carrfreq, c.ti));
-        GcFillRecord fr{rk};
-        gc_carrier_period(PK, remcarr, n, fr, &dummy);
+    int4 *rc = reinterpret_cast<int4 *>(claims_code) + (size_t)i * (GC_CLAIM_ROW / 4);
+    int4 *rk = reinterpret_cast<int4 *>(claims_car) + (size_t)i * (GC_CLAIM_ROW / 4);
+    const int *pc = reinterpret_cast<const int *>(&cc), *pk = reinterpret_cast<const int *>(&ck);
+#pragma unroll
+    for (int q = 0; q < GC_CLAIM_ROW / 4; q++) {
+        rc[q] = make_int4(pc[4 * q], pc[4 * q + 1], pc[4 * q + 2], pc[4 * q + 3]);
+        rk[q] = make_int4(pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]);
     }
 }
 
-// which path served the periods of the batches planned so far: [0] code speculated, [1] code certified,
+// which path served the periods of the batches planned so far: [0] code on claims, [1] code certified,
 // [2] code walkers, [3..5] the same for the carrier (tools/debug, tests)
 __device__ unsigned long long gc_plan_stats[8];
+
+// Which instance of the batch chain serves a channel: the table binade that holds the code length (the shape
+// of the code step: 2..64 samples per chip give 7..12) and whether the tail fits 8 positions.  -1: none
+// (the chain below serves it).  Host and device use the same function.
+__host__ __device__ inline int plan2_class(double ti, double codefreq, int clen, int smax)
+{
+    const double ci = ti * codefreq;
+    const uint64_t us = gc_d2u(ci);
+    const int es = (int)((us >> 52) & 0x7FF);
+    if (!(ci > 0.0) || es <= 60 || es >= 0x7FF - GC_NB - 4) return -1;
+    const int itop = gc_expo(gc_u2d(gc_d2u((double)clen) - 1)) - (es + 2);
+    if (itop < 7 || itop > 12) return -1;
+    return (itop - 7) * 2 + (smax + 1 > 8 ? 1 : 0);
+}
 
 // Two wavefronts per channel: wavefront 0 chains the code NCO (and with it the samples per period and the
 // buffer positions), wavefront 1 follows one step behind with the carrier NCO, which needs only the
@@ -100,14 +125,15 @@ __device__ unsigned long long gc_plan_stats[8];
 __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict__ chan,
                                                        const GcTrkState *__restrict__ state_in,
                                                        GcTrkState *__restrict__ state_out,
-                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch,
-                                                       const int *__restrict__ spec_code, const int *__restrict__ spec_car, int dbg)
+                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch, unsigned classmask)
 {
     __shared__ int Ks2[2][GC_NB + 2];
     __shared__ int nsh[GC_PLAN_MAXE];
     __shared__ int prog;
     const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (ch >= nch) return;
+    // the channels the batch chain serves (trk_plan2_kernel, launched beside this one)
+    if (classmask && plan2_class(chan[ch].ti, state_in[ch].codefreq, chan[ch].clen, chan[ch].smax) >= 0) return;
     // the chain is latency bound and shares its SIMD with correlator wavefronts of the batch before:
     // let it issue first
     __builtin_amdgcn_s_setprio(3);
@@ -137,31 +163,9 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
     const double yspc = __ddiv_rn(1.0, spc), ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
     const double smaxci = __dmul_rn((double)c.smax, ci);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
-    // the speculated crossings of the period after the one at hand are fetched a period ahead (the rows
-    // are read through the scalar cache: wave-uniform addresses)
-    const bool spec = spec_code != nullptr && spec_car != nullptr;
-    const int4 *rowc = reinterpret_cast<const int4 *>(spec_code) + (size_t)ch * nepoch * (GC_SPEC_ROW / 4);
-    const int4 *rowk = reinterpret_cast<const int4 *>(spec_car) + (size_t)ch * nepoch * (GC_SPEC_ROW / 4);
-    GcFillSpec nxc, nxk;
-    auto fetch = [&](GcFillSpec &f, const int4 *rows, int e) {
-#pragma unroll
-        for (int q = 0; q < GC_SPEC_ROW / 4; q++) {
-            const int4 v = rows[(size_t)e * (GC_SPEC_ROW / 4) + q];
-            f.k[4 * q] = v.x; f.k[4 * q + 1] = v.y; f.k[4 * q + 2] = v.z; f.k[4 * q + 3] = v.w;
-        }
-    };
-#pragma unroll
-    for (int q = 0; q < GC_SPEC_ROW; q++) { nxc.k[q] = 0; nxk.k[q] = 0; }
-    if (spec && do_code) fetch(nxc, rowc, 0);
-    if (spec && do_car) fetch(nxk, rowk, 0);
     unsigned tally[6] = {0, 0, 0, 0, 0, 0};
     for (int e = 0; e < nepoch; e++) {
         int n;
-        GcFillSpec cuc = nxc, cuk = nxk;
-        if (spec && e + 1 < nepoch) {
-            if (do_code) fetch(nxc, rowc, e + 1);
-            if (do_car) fetch(nxk, rowk, e + 1);
-        }
         if (do_code) {
             const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
             const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
@@ -184,14 +188,11 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
             n = nsh[e];
         }
         const bool walk = n > 0 && n <= (1 << 24);
-        if (do_car && !(dbg & 2)) {
+        if (do_car) {
             if (lane == 0) out[e].phi0 = s.remcarr;
             double rp;
-            if (walk && spec && gc_carrier_period(PK, s.remcarr, n, cuk, &rp)) {
-                s.remcarr = rp;     // (speculated crossings, checked)
-                tally[3]++;
-            } else if (walk && gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
-                s.remcarr = rp;     // (crossings certified here, one per lane)
+            if (walk && gc_carrier_period(PK, s.remcarr, n, fill, &rp)) {
+                s.remcarr = rp;
                 tally[4]++;
             } else if (walk) {      // any other shape: the general walkers
                 tally[5]++;
@@ -201,13 +202,9 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
                 s.remcarr = gc_fast_prem(fprem, xn);
             }
         }
-        if (do_code && (dbg & 1)) s.buffloc += (uint64_t)(int64_t)n;
-        if (do_code && !(dbg & 1)) {
+        if (do_code) {
             double rc;
-            if (walk && code_ok && spec && gc_code_period_inl(PC, s.remcode, n + 2 * c.smax, cuc, &rc)) {
-                s.remcode = rc;
-                tally[0]++;
-            } else if (walk && code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
+            if (walk && code_ok && gc_code_period(PC, s.remcode, n + 2 * c.smax, fill, &rc)) {
                 s.remcode = rc;
                 tally[1]++;
             } else if (walk && code_ok) {
@@ -232,6 +229,370 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
 #pragma unroll
         for (int t = 0; t < 6; t++)
             if (tally[t]) atomicAdd(&gc_plan_stats[t], (unsigned long long)tally[t]);
+    }
+}
+
+// ---- the batch planner's chain: evaluate and check (gnsscorr_nco.h: "period steps on claims") ----
+// Same two wavefronts per channel.  Each stages the claims of GC_PLAN_BLK periods at a time in LDS (the next
+// block's rows are in flight while this one is evaluated), keeps the periods' results in its lanes (lane l:
+// period l of the block) and writes them out once per block; the carrier wavefront starts a block when the
+// code wavefront has finished it, so the period lengths it needs are all there.
+#define GC_PLAN_BLK 32
+struct Plan2Shared {
+    int Ks2[2][GC_NB + 2];
+    int nsh[GC_PLAN_MAXE];
+    int prog;
+    int pad[3];
+    int rows[2][2][GC_PLAN_BLK * GC_CLAIM_ROW];
+};
+
+#ifdef GC_PLAN_PROF
+__device__ unsigned long long gc_plan_prof[16];
+#define GC_PP(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); pp[i] += t1_ - pp_t; pp_t = t1_; } while (0)
+#else
+#define GC_PP(i) do { } while (0)
+#endif
+// (file scope: the two wave functions below are called, not inlined -- each instance of the code step gets its
+// own register allocation -- and reach the workgroup's LDS by name)
+__shared__ __attribute__((aligned(16))) Plan2Shared g_plan2;
+
+// (arguments of a called function arrive in vector registers: what is the same in every lane is said so)
+__device__ __forceinline__ int plan2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T *plan2_uni(T *p)
+{
+    const uint64_t u = (uint64_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double plan2_uni(double x)
+{
+    const uint64_t u = gc_d2u(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return gc_u2d(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void plan2_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A period whose claims did not hold (a few in ten thousand): the certified step, then the walkers, with the
+// tables they need built here -- out of line, so that the chain's loop carries none of it.
+// returns 1: certified step, 2: walkers
+__device__ __attribute__((noinline)) int plan2_code_slow(double ci_, int clen_, int smax_, double remcode_, int n_, int lane, double *out)
+{
+    const double ci = plan2_uni(ci_), remcode = plan2_uni(remcode_);
+    const int clen = plan2_uni(clen_), smax = plan2_uni(smax_), n = plan2_uni(n_);
+    GcCodePlan PC;
+    gc_code_plan_init(PC, ci, clen, smax);
+    GcFillLanes fill{lane};
+    GcNoEmit ne;
+    double rc;
+    if (gc_code_period(PC, remcode, n + 2 * smax, fill, &rc)) { *out = rc; return 1; }
+    const double smaxci = __dmul_rn((double)smax, ci);
+    const double c0 = gc_code_start_fast(remcode, smaxci, clen);
+    double cend;
+    if (!plan_code_dev(PC.f, c0, clen, n + 2 * smax, g_plan2.Ks2[0], lane, &cend))
+        cend = gc_fast_code_walk(PC.f, c0, clen, n + 2 * smax, ne);
+    *out = __dsub_rn(cend, smaxci);
+    return 2;
+}
+
+__device__ __attribute__((noinline)) int plan2_car_slow(double ps_, double remcarr_, int n_, int lane, double *out)
+{
+    const double ps = plan2_uni(ps_), remcarr = plan2_uni(remcarr_);
+    const int n = plan2_uni(n_);
+    GcCarPlan PK;
+    gc_car_plan_init(PK, ps);
+    GcFillLanes fill{lane};
+    GcNoEmit ne;
+    double rp;
+    if (gc_carrier_period(PK, remcarr, n, fill, &rp)) { *out = rp; return 1; }
+    const double phis = gc_div_y(__dmul_rn(remcarr, GC_NCO_CDIV), GC_NCO_DPI, __ddiv_rn(1.0, GC_NCO_DPI));     // ref src/sdrcmn.c:649
+    double xn;
+    if (!plan_carrier_dev(PK.f, phis, n, g_plan2.Ks2[1], lane, &xn)) xn = gc_fast_carrier_walk(PK.f, phis, n, ne);
+    *out = gc_fast_prem(PK.fprem, xn);
+    return 2;
+}
+
+template <int ITOP, int TMAX>
+__device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTrkState s_, GcTrkState *__restrict__ state_out_,
+                                                GcTrkPlan *__restrict__ out_, int nepoch_, const int4 *__restrict__ src_, int lane, int dbg_)
+{
+    // the channel constants the loop needs, as values (the reference points into the caller's frame)
+    struct { double ti, f_sf; int clen, smax; } c;
+    c.ti = plan2_uni(c_.ti);
+    c.f_sf = plan2_uni(c_.f_sf);
+    c.clen = plan2_uni(c_.clen);
+    c.smax = plan2_uni(c_.smax);
+    GcTrkState s;
+    s.carrfreq = plan2_uni(s_.carrfreq);
+    s.codefreq = plan2_uni(s_.codefreq);
+    s.remcode = plan2_uni(s_.remcode);
+    s.remcarr = plan2_uni(s_.remcarr);
+    s.buffloc = gc_d2u(plan2_uni(gc_u2d(s_.buffloc)));
+    GcTrkState *__restrict__ state_out = plan2_uni(state_out_);
+    GcTrkPlan *__restrict__ out = plan2_uni(out_);
+    const int4 *__restrict__ src = plan2_uni(src_);
+    const int nepoch = plan2_uni(nepoch_), dbg = plan2_uni(dbg_);
+    const double ci = __dmul_rn(c.ti, s.codefreq);
+    const double spc = __ddiv_rn(s.codefreq, c.f_sf);
+    const double dlen = (double)c.clen;
+    const bool code_ok = ci > 0.0 && ci < dlen;
+    GcCodePlan PC;
+    gc_code_plan_init(PC, ci, c.clen, c.smax);
+    GcCodeStepC<ITOP> SC;
+    gc_code_stepc_init(SC, PC);
+    const double yspc = __ddiv_rn(1.0, spc);
+    const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
+    int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[0];
+    constexpr int RQ = GC_CLAIM_ROW / 4;
+    unsigned tally[3] = {0, 0, 0};
+#ifdef GC_PLAN_PROF
+    unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
+#endif
+    const int nblk = (nepoch + GC_PLAN_BLK - 1) / GC_PLAN_BLK;
+    int4 pf[RQ];
+    auto fetch_block = [&](int b) {
+        const int e = b * GC_PLAN_BLK + lane;
+        if (lane < GC_PLAN_BLK && e < nepoch) {
+#pragma unroll
+            for (int q = 0; q < RQ; q++) pf[q] = src[(size_t)e * RQ + q];
+        }
+    };
+    auto store_block = [&](int buf) {
+        if (lane < GC_PLAN_BLK) {
+#pragma unroll
+            for (int q = 0; q < RQ; q++) reinterpret_cast<int4 *>(rows[buf])[lane * RQ + q] = pf[q];
+        }
+        plan2_wave_sync();
+    };
+#pragma unroll
+    for (int q = 0; q < RQ; q++) pf[q] = make_int4(0, 0, 0, 0);
+    fetch_block(0);
+    store_block(0);
+    for (int b = 0; b < nblk; b++) {
+        const int buf = b & 1, e0 = b * GC_PLAN_BLK;
+        const int e1 = e0 + GC_PLAN_BLK < nepoch ? e0 + GC_PLAN_BLK : nepoch;
+        if (b + 1 < nblk) fetch_block(b + 1);
+        uint64_t k_buff = 0;
+        double k_coff = 0.0;
+        int k_n = 0;
+        GcCodeClaims nx;
+        {
+            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]);
+            int4 v[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; q++) v[q] = r[q];
+            memcpy(&nx, v, sizeof(nx));
+        }
+        for (int e = e0; e < e1; e++) {
+            GC_PP(0);
+            GcCodeClaims cl = nx;
+            if (e + 1 < e1) {                       // the next period's claims, in flight during this one
+                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ;
+                int4 v[RQ];
+#pragma unroll
+                for (int q = 0; q < RQ; q++) v[q] = r[q];
+                memcpy(&nx, v, sizeof(nx));
+            }
+            const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
+            const double qn = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
+            const int n = (qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0;
+            const bool mine = lane == e - e0;
+            k_buff = mine ? s.buffloc : k_buff;
+            k_coff = mine ? s.remcode : k_coff;
+            k_n = mine ? n : k_n;
+            g_plan2.nsh[e] = n;                          // (every lane, the same value)
+            GC_PP(1);
+            const bool walk = n > 0 && n <= (1 << 24) && code_ok && !(dbg & 1);
+            double rc, rcf;
+            if (__builtin_expect(walk && gc_code_claims_step<ITOP, TMAX, false>(PC, SC, s.remcode, n + 2 * c.smax, cl, &rcf), 1)) {
+                s.remcode = rcf;
+                tally[0]++;
+            } else if (walk) {
+                tally[plan2_code_slow(ci, c.clen, c.smax, s.remcode, n, lane, &rc)]++;
+                s.remcode = rc;
+            }
+            s.buffloc += (uint64_t)(int64_t)n;
+            GC_PP(2);
+        }
+        if (lane < e1 - e0) {
+            GcTrkPlan &o = out[e0 + lane];
+            o.buffloc = k_buff;
+            o.coff = k_coff;
+            o.carrfreq = s.carrfreq;
+            o.codefreq = s.codefreq;
+            o.n = k_n;
+            o.pad = 0;
+        }
+        __threadfence_block();
+        if (lane == 0) __hip_atomic_store(&g_plan2.prog, e1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (b + 1 < nblk) store_block(buf ^ 1);
+        GC_PP(3);
+    }
+#ifdef GC_PLAN_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 4; i++) atomicAdd(&gc_plan_prof[i], pp[i]);
+#endif
+    if (lane == 0) {
+        state_out->carrfreq = s.carrfreq;
+        state_out->codefreq = s.codefreq;
+        state_out->remcode = s.remcode;
+        state_out->buffloc = s.buffloc;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (tally[t]) atomicAdd(&gc_plan_stats[t], (unsigned long long)tally[t]);
+    }
+}
+
+__device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrkState s_, GcTrkState *__restrict__ state_out_,
+                                               GcTrkPlan *__restrict__ out_, int nepoch_, const int4 *__restrict__ src_, int lane, int dbg_)
+{
+    struct { double ti; int nsamp; } c;
+    c.ti = plan2_uni(c_.ti);
+    c.nsamp = plan2_uni(c_.nsamp);
+    GcTrkState s;
+    s.carrfreq = plan2_uni(s_.carrfreq);
+    s.codefreq = plan2_uni(s_.codefreq);
+    s.remcode = plan2_uni(s_.remcode);
+    s.remcarr = plan2_uni(s_.remcarr);
+    s.buffloc = s_.buffloc;
+    GcTrkState *__restrict__ state_out = plan2_uni(state_out_);
+    GcTrkPlan *__restrict__ out = plan2_uni(out_);
+    const int4 *__restrict__ src = plan2_uni(src_);
+    const int nepoch = plan2_uni(nepoch_), dbg = plan2_uni(dbg_);
+    const double ps = gc_carrier_ps(s.carrfreq, c.ti);
+    GcCarPlan PK;
+    gc_car_plan_init(PK, ps, false, false);
+    GcCarStepC CK;
+    gc_car_stepc_init(CK, PK, c.nsamp + 16);
+    int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[1];
+    constexpr int RQ = GC_CLAIM_ROW / 4;
+    unsigned tally[3] = {0, 0, 0};
+#ifdef GC_PLAN_PROF
+    unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
+#endif
+    const int nblk = (nepoch + GC_PLAN_BLK - 1) / GC_PLAN_BLK;
+    int4 pf[RQ];
+    auto fetch_block = [&](int b) {
+        const int e = b * GC_PLAN_BLK + lane;
+        if (lane < GC_PLAN_BLK && e < nepoch) {
+#pragma unroll
+            for (int q = 0; q < RQ; q++) pf[q] = src[(size_t)e * RQ + q];
+        }
+    };
+    auto store_block = [&](int buf) {
+        if (lane < GC_PLAN_BLK) {
+#pragma unroll
+            for (int q = 0; q < RQ; q++) reinterpret_cast<int4 *>(rows[buf])[lane * RQ + q] = pf[q];
+        }
+        plan2_wave_sync();
+    };
+#pragma unroll
+    for (int q = 0; q < RQ; q++) pf[q] = make_int4(0, 0, 0, 0);
+    fetch_block(0);
+    store_block(0);
+    for (int b = 0; b < nblk; b++) {
+        const int buf = b & 1, e0 = b * GC_PLAN_BLK;
+        const int e1 = e0 + GC_PLAN_BLK < nepoch ? e0 + GC_PLAN_BLK : nepoch;
+        if (b + 1 < nblk) fetch_block(b + 1);
+        // the code wavefront has finished this block: its period lengths are in nsh[]
+        while (__hip_atomic_load(&g_plan2.prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < e1) __builtin_amdgcn_s_sleep(1);
+        double k_phi = 0.0;
+        GcCarClaims nx;
+        int nn;
+        {
+            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]);
+            int4 v[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; q++) v[q] = r[q];
+            memcpy(&nx, v, sizeof(nx));
+            nn = g_plan2.nsh[e0];
+        }
+        GC_PP(4);
+        for (int e = e0; e < e1; e++) {
+            GC_PP(5);
+            GcCarClaims cl = nx;
+            const int n = nn;
+            if (e + 1 < e1) {
+                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ;
+                int4 v[RQ];
+#pragma unroll
+                for (int q = 0; q < RQ; q++) v[q] = r[q];
+                memcpy(&nx, v, sizeof(nx));
+                nn = g_plan2.nsh[e + 1];
+            }
+            const bool mine = lane == e - e0;
+            k_phi = mine ? s.remcarr : k_phi;
+            GC_PP(6);
+            const bool walk = n > 0 && n <= (1 << 24) && !(dbg & 2);
+            double rp, rpf;
+            if (__builtin_expect(walk && gc_carrier_claims_step<false>(PK, CK, s.remcarr, n, cl, &rpf), 1)) {
+                s.remcarr = rpf;
+                tally[0]++;
+            } else if (walk) {
+                tally[plan2_car_slow(ps, s.remcarr, n, lane, &rp)]++;
+                s.remcarr = rp;
+            }
+            GC_PP(7);
+        }
+        GC_PP(5);
+        if (lane < e1 - e0) out[e0 + lane].phi0 = k_phi;
+        if (b + 1 < nblk) store_block(buf ^ 1);
+    }
+#ifdef GC_PLAN_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        for (int i = 4; i < 8; i++) atomicAdd(&gc_plan_prof[i], pp[i]);
+#endif
+    if (lane == 0) {
+        state_out->remcarr = s.remcarr;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (tally[t]) atomicAdd(&gc_plan_stats[3 + t], (unsigned long long)tally[t]);
+    }
+}
+
+__global__ __launch_bounds__(128) void trk_plan2_kernel(const GcChan *__restrict__ chan,
+                                                        const GcTrkState *__restrict__ state_in,
+                                                        GcTrkState *__restrict__ state_out,
+                                                        GcTrkPlan *__restrict__ plan, int nch, int nepoch,
+                                                        const int *__restrict__ claims_code, const int *__restrict__ claims_car, int dbg)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (ch >= nch) return;
+    const int cls = plan2_class(chan[ch].ti, state_in[ch].codefreq, chan[ch].clen, chan[ch].smax);
+    if (cls < 0) return;            // (trk_plan_kernel serves it)
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) g_plan2.prog = 0;
+    __syncthreads();
+    const GcChan c = chan[ch];
+    const GcTrkState s = state_in[ch];
+    GcTrkPlan *out = plan + (size_t)ch * nepoch;
+    constexpr int RQ = GC_CLAIM_ROW / 4;
+    if (wave == 1) {
+        plan2_car_wave(c, s, state_out + ch, out, nepoch, reinterpret_cast<const int4 *>(claims_car) + (size_t)ch * nepoch * RQ, lane, dbg);
+        return;
+    }
+    const int4 *src = reinterpret_cast<const int4 *>(claims_code) + (size_t)ch * nepoch * RQ;
+    switch (cls) {
+    case 0:  plan2_code_wave<7, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 1:  plan2_code_wave<7, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 2:  plan2_code_wave<8, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 3:  plan2_code_wave<8, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 4:  plan2_code_wave<9, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 5:  plan2_code_wave<9, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 6:  plan2_code_wave<10, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 7:  plan2_code_wave<10, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 8:  plan2_code_wave<11, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 9:  plan2_code_wave<11, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 10: plan2_code_wave<12, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    default: plan2_code_wave<12, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     }
 }
 
@@ -736,7 +1097,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     using L = PsLayout<DTYPE, NIT>;
     constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, LPAD = L::LPAD;
     const int ntap = c.ntap;
-    const int n = u.n, smax = c.smax, clen = c.clen, head = u.head, G = u.G;
+    const int n = u.n, smax = c.smax, head = u.head, G = u.G;
     const int g0 = seg * RGRP * rpw;
     // nothing to correlate (trk_expand: outside the reference's scratch, undefined chip step, NCO table
     // overflow) or nothing left for this workgroup
@@ -1523,6 +1884,13 @@ void trk_pick_nit()
 
 }  // namespace
 
+#ifdef GC_PLAN_PROF
+extern "C" int gnsscorr_debug_plan_prof(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_plan_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int gnsscorr_debug_plan_stats(unsigned long long *dst, int reset)
 {
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_plan_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
@@ -1549,25 +1917,32 @@ static bool trk_nospec()
     return nospec;
 }
 
-// spec: 2 * nch * nepoch * GC_SPEC_ROW ints of scratch for the speculated crossings
-int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *spec)
+// claims: 2 * nch * nepoch * GC_CLAIM_ROW ints of scratch (code rows, then carrier rows)
+int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims)
 {
-    if (!spec || trk_nospec()) return 0;
+    if (!claims || trk_nospec() || nepoch > GC_PLAN_MAXE) return 0;
     const int total = nch * nepoch;
-    hipLaunchKernelGGL(trk_spec_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, state_in, spec,
-                       spec + (size_t)nch * nepoch * GC_SPEC_ROW, nch, nepoch);
+    hipLaunchKernelGGL(trk_spec_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, state_in, claims,
+                       claims + (size_t)nch * nepoch * GC_CLAIM_ROW, nch, nepoch);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
-// spec: filled by gc_launch_trk_spec for the same state and batch (null: the chain certifies its
-// crossings itself, period by period)
+// claims: filled by gc_launch_trk_spec for the same state and batch -> the batch form of the chain (evaluate and
+// check) for every channel it has an instance for (plan2_class); the chain that certifies its crossings itself,
+// period by period, serves the rest -- and everything when claims is null or the batch is longer than
+// GC_PLAN_MAXE periods.
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
-                       GcTrkPlan *plan, int nch, int nepoch, int *spec)
+                       GcTrkPlan *plan, int nch, int nepoch, int *claims)
 {
-    int *sc = (spec && !trk_nospec()) ? spec : nullptr, *sk = sc ? sc + (size_t)nch * nepoch * GC_SPEC_ROW : nullptr;
-    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan,
-                       nch, nepoch, sc, sk, getenv("GNSSCORR_PLAN_DBG") ? atoi(getenv("GNSSCORR_PLAN_DBG")) : 0);
+    static const int dbg = getenv("GNSSCORR_PLAN_DBG") ? atoi(getenv("GNSSCORR_PLAN_DBG")) : 0;
+    const bool batch = claims && !trk_nospec() && nepoch <= GC_PLAN_MAXE;
+    if (batch) {
+        hipLaunchKernelGGL(trk_plan2_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch,
+                           claims, claims + (size_t)nch * nepoch * GC_CLAIM_ROW, dbg);
+        GC_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch, batch ? 1u : 0u);
     GC_HIP(hipGetLastError());
     return 0;
 }

@@ -154,13 +154,11 @@ int nco_period_tables(double ti, double freq, double remcarr, double codefreq, i
     return r;
 }
 
-// The planner's batch: crossings speculated from closed-form period starts (trk_spec_kernel), then the chain
-// that checks them (trk_plan_kernel), with the certified fill and the walkers behind it.  State after every
-// period, and how many periods each path served (hits[0]: speculated code, [1]: speculated carrier,
-// [2]: certified code, [3]: certified carrier, [4]: walkers code, [5]: walkers carrier).
-// shift: added to the speculation's start values (a test's way of making the claims wrong).
-void nco_spec_chain(double ti, double f_sf, double freq, double codefreq, int len, int smax, double remcode0, double remcarr0,
-                    int nepoch, double shift_code, double shift_car, double *rem_out, double *prem_out, int *n_out, int *hits)
+// The batch planner's steps on claims (trk_spec_kernel discovers, trk_plan2_kernel evaluates): state after every
+// period; hits[0]/[1]: periods the code / carrier evaluation served, the rest go to the certified steps
+// ([2]/[3]) and the walkers ([4]/[5]).  shift_*: added to the discovering run's start values.
+void nco_claims_chain(double ti, double f_sf, double freq, double codefreq, int len, int smax, double remcode0, double remcarr0,
+                      int nepoch, double shift_code, double shift_car, double *rem_out, double *prem_out, int *n_out, int *hits)
 {
     GC_FP_STRICT
     const double ci = ti * codefreq, spc = codefreq / f_sf, ps = gc_carrier_ps(freq, ti), dlen = (double)len;
@@ -169,38 +167,38 @@ void nco_spec_chain(double ti, double f_sf, double freq, double codefreq, int le
     gc_code_plan_init(PC, ci, len, smax);
     gc_car_plan_init(PK, ps);
     GcNcoFast fcode = PC.f, fcar = PK.f;
+    GcCarStepC CK;
+    gc_car_stepc_init(CK, PK, (int)(f_sf * 1e-3) + 16);
     const double smaxci = (double)smax * ci, ydpi = 1.0 / GC_NCO_DPI;
     GcNoEmit ne;
     double remcode = remcode0, remcarr = remcarr0;
     for (int i = 0; i < 6; i++) hits[i] = 0;
     for (int e = 0; e < nepoch; e++) {
-        // speculation (parallel on the device)
-        GcFillSpec sc, sk;
-        sc.k[GC_NB + 1] = 0;
-        sk.k[GC_NB + 1] = 0;
+        GcCodeClaims cc;
+        GcCarClaims ck;
+        cc.tag = 0;
+        ck.tag = 0;
         {
             double rc, rk, dummy;
             int ns;
             gc_spec_start(remcode0, remcarr0, ci, spc, ps, dlen, e, &rc, &rk, &ns);
             if (ns > 0) {
-                GcFillRecord frc{sc.k}, frk{sk.k};
-                gc_code_period(PC, rc + shift_code, ns + 2 * smax, frc, &dummy);
-                gc_carrier_period(PK, rk + shift_car, ns, frk, &dummy);
+                gc_code_claims<true>(PC, rc + shift_code, ns + 2 * smax, cc, &dummy);
+                gc_carrier_claims_step<true>(PK, CK, rk + shift_car, ns, ck, &dummy);
             }
         }
-        // chain
         const int n = (int)((dlen - remcode) / spc);
         n_out[e] = n;
         double r;
         GcFillLoop fill;
-        if (gc_carrier_period(PK, remcarr, n, sk, &r)) hits[1]++;
+        if (gc_carrier_claims_step<false>(PK, CK, remcarr, n, ck, &r)) hits[1]++;
         else if (gc_carrier_period(PK, remcarr, n, fill, &r)) hits[3]++;
         else {
             hits[5]++;
             r = gc_fast_prem(PK.fprem, gc_fast_carrier_walk(fcar, gc_div_y(remcarr * GC_NCO_CDIV, GC_NCO_DPI, ydpi), n, ne));
         }
         remcarr = r;
-        if (gc_code_period(PC, remcode, n + 2 * smax, sc, &r)) hits[0]++;
+        if (gc_code_claims<false>(PC, remcode, n + 2 * smax, cc, &r)) hits[0]++;
         else if (gc_code_period(PC, remcode, n + 2 * smax, fill, &r)) hits[2]++;
         else {
             hits[4]++;

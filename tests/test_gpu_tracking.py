@@ -270,9 +270,16 @@ def test_planner_chain_long_batch(gc, orc, engine):
         s["carrfreq"] = float(rng.uniform(-9000, 9000)) * (-1 if i % 2 else 1)
         s["codefreq"] = chans[i].crate + float(rng.uniform(-8, 8))
     engine.trk_set_state(states)
+    stats = np.zeros(8, dtype=np.uint64)
+    gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
     engine.trk_run(nepoch)
     II, QQ, ns = engine.trk_fetch()
     fin = engine.trk_get_state()
+    # the batch form of the planner (periods discovered side by side, evaluated and checked in the chain) is
+    # what serves these channels; the certified step and the walkers take what it declines
+    gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
+    assert stats[:3].sum() >= len(chans) * nepoch and stats[3:6].sum() >= len(chans) * nepoch, stats
+    assert stats[0] >= 0.95 * stats[:3].sum() and stats[3] >= 0.8 * stats[3:6].sum(), stats
     oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch)
     assert np.array_equal(ns, ons)
     for a, b in zip(fin, ofin):

@@ -31,7 +31,7 @@ def nco(tmp_path_factory):
     L.nco_code_period.argtypes = [d, d, i, d, i, i, C.POINTER(d)]
     L.nco_carrier_period.argtypes = [d, d, d, i, C.POINTER(d)]
     L.nco_period_tables.argtypes = [d, d, d, d, i, d, i, i, vp, vp, C.POINTER(d), C.POINTER(d)]
-    L.nco_spec_chain.argtypes = [d, d, d, d, i, i, d, d, i, d, d, vp, vp, vp, vp]
+    L.nco_claims_chain.argtypes = [d, d, d, d, i, i, d, d, i, d, d, vp, vp, vp, vp]
     L.nco_carrier_fast.argtypes = L.nco_carrier.argtypes
     L.nco_code_fast.argtypes = L.nco_code.argtypes
     return L
@@ -255,30 +255,52 @@ def _literal_chain(orc, carrfreq, codefreq, remcode, remcarr, nper, smax=6, leng
 
 
 @pytest.mark.parametrize("shift_code,shift_car", [(0.0, 0.0), (0.03, 0.005), (-3e-9, 2e-9)])
-def test_speculated_crossings_are_checked_by_the_chain(nco, orc, shift_code, shift_car):
-    """The planner's batch form (trk_spec_kernel + trk_plan_kernel): binade crossings speculated for all
-    periods at once from closed-form period starts, checked by the sequential chain.  Every chained value
-    equals the literal loops' -- also when the speculation is fed start values that are off by half a
-    sample (its claims are then wrong and the chain must notice) -- and with honest start values the
-    speculated path is the one that serves nearly every period."""
+def test_period_steps_on_claims(nco, orc, shift_code, shift_car):
+    """The batch planner's branch-free form (gc_code_claims_step / gc_carrier_claims_step): the structure of
+    every period discovered from closed-form starts, evaluated and checked from the exact ones.  Every chained
+    value equals the literal loops'; with honest starts the evaluation serves nearly every period."""
     ti = 1 / F_SF
     nper = 250
     cases = [(2200.3, 1.023e6 + 1.4, 0.31, 1.7), (-1400.7, 1.023e6 - 2.7, 511.2, 0.0), (137.77, 1.023e6 + 2.9, 0.0, 6.1),
-             (4999.1, 1.023e6 - 0.01, 1022.4, 3.3), (-4876.2, 1.023e6 + 3.1, 17.0, -40.0), (0.0, 1.023e6, 0.0, 0.0)]
+             (4999.1, 1.023e6 - 0.01, 1022.4, 3.3), (-4876.2, 1.023e6 + 3.1, 17.0, -40.0), (0.0, 1.023e6, 0.0, 0.0),
+             (6200.0, 1.023e6 + 0.7, 3.0, 0.001), (-12.5, 1.023e6 - 1.1, 800.0, 2.0)]
     for carrfreq, codefreq, remcode0, remcarr0 in cases:
         orem, oprem, on = _literal_chain(orc, carrfreq, codefreq, remcode0, remcarr0, nper)
         rem, prem = np.zeros(nper), np.zeros(nper)
         n, hits = np.zeros(nper, np.int32), np.zeros(6, np.int32)
-        nco.nco_spec_chain(ti, F_SF, carrfreq, codefreq, 1023, 6, remcode0, remcarr0, nper, shift_code, shift_car,
-                           rem.ctypes.data, prem.ctypes.data, n.ctypes.data, hits.ctypes.data)
+        nco.nco_claims_chain(ti, F_SF, carrfreq, codefreq, 1023, 6, remcode0, remcarr0, nper, shift_code, shift_car,
+                             rem.ctypes.data, prem.ctypes.data, n.ctypes.data, hits.ctypes.data)
         assert np.array_equal(n, on), (carrfreq, codefreq)
         assert np.array_equal(rem, orem), (carrfreq, codefreq, hits)
         assert np.array_equal(prem, oprem), (carrfreq, codefreq, hits)
-        if shift_code == 0.0 and carrfreq != 0.0 and codefreq != 1.023e6:
-            assert hits[0] >= nper - 5 and hits[1] >= nper - 5, (carrfreq, codefreq, hits)
-        # (shifted start values: whatever claims still pass are right -- the code's boundaries are multiples of
-        # the nominal chip step 1/16, so its crossings hardly depend on the start value; the values above
-        # are what counts)
+        # (a slowly falling phase that is still positive shrinks towards zero: not a shape of the period steps,
+        # the walkers serve it until it has changed sign)
+        # A falling phase is never wrapped: while it is small, a period now and then crosses into the next
+        # binade above the evaluation's window and goes to the certified step.
+        if shift_code == 0.0 and abs(carrfreq) > 100.0 and codefreq != 1.023e6:
+            assert hits[0] >= nper - 5 and hits[1] >= nper - 15, (carrfreq, codefreq, hits)
+
+
+def test_period_steps_on_claims_random_channels(nco, orc):
+    """random channel states (tie binades of the chip step included: about half of all step values have
+    one inside the table), 60 periods each"""
+    rng = np.random.default_rng(77)
+    ti = 1 / F_SF
+    nper = 60
+    served = np.zeros(2, np.int64)
+    for _ in range(40):
+        carrfreq = float(rng.uniform(-6000, 6000))
+        codefreq = 1.023e6 + float(rng.uniform(-3, 3))
+        remcode0, remcarr0 = float(rng.uniform(0, 1023)), float(rng.uniform(0, 6.28))
+        orem, oprem, on = _literal_chain(orc, carrfreq, codefreq, remcode0, remcarr0, nper)
+        rem, prem = np.zeros(nper), np.zeros(nper)
+        n, hits = np.zeros(nper, np.int32), np.zeros(6, np.int32)
+        nco.nco_claims_chain(ti, F_SF, carrfreq, codefreq, 1023, 6, remcode0, remcarr0, nper, 0.0, 0.0,
+                             rem.ctypes.data, prem.ctypes.data, n.ctypes.data, hits.ctypes.data)
+        assert np.array_equal(n, on) and np.array_equal(rem, orem) and np.array_equal(prem, oprem), \
+            (carrfreq, codefreq, remcode0, remcarr0, hits)
+        served += hits[:2]
+    assert served[0] >= 0.97 * 40 * nper and served[1] >= 0.90 * 40 * nper, served
 
 
 def test_certified_chain_random_states(nco, orc):
