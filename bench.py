@@ -346,6 +346,34 @@ def main():
                         "correlations_per_s": NCH * NP * ntap / cdt}
         out["closed_loop"] = cl
 
+    # ---- host-fed leg: the IF stream comes from host memory (gnsscorr_ring_push: pinned double buffer and
+    # copy stream; the PCIe-inclusive rate, never `value`) ------------------
+    if world == 1 and rank == 0 and not os.environ.get("BENCH_NO_HOSTFED"):
+        log("host-fed leg")
+        eng2 = gc.Engine(dev_index)
+        eng2.ring_create(1, 2, ringlen)
+        eng2.set_channels(chans)
+        hostbytes = np.ascontiguousarray(data.reshape(-1))
+        eng2.ring_push_raw(1, hostbytes, chunk)
+        eng2.ring_push_raw(1, hostbytes, chunk)
+        eng2.trk_set_state(states0)
+        nl = 12
+        for _ in range(2):                  # warm-up
+            eng2.ring_push_raw(1, hostbytes, chunk)
+            eng2.trk_run(E)
+        eng2.sync()
+        t0 = time.perf_counter()
+        for _ in range(nl):
+            eng2.ring_push_raw(1, hostbytes, chunk)
+            eng2.trk_run(E)
+        eng2.sync()
+        hdt = time.perf_counter() - t0
+        out["host_fed"] = {"x_realtime": nl * E / hdt / 1000.0, "correlations_per_s": NCH * E * nl * ntap / hdt,
+                           "host_to_ring_GBps": nl * chunk * 2 / hdt / 1e9,
+                           "note": "every launch's IF chunk (32.7 MB) pushed from pageable host memory through the pinned "
+                                   "double buffer and the copy stream, overlapped with the previous launch's kernels"}
+        eng2.close()
+
     # ---- acquisition leg (configs[1]) --------------------------------------
     if not args.no_acq:
         log("acquisition leg")

@@ -1293,6 +1293,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                     }
                 }
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                // the group's LUT entries first, all in flight together (the image writes below could alias
+                // them as far as the compiler knows, and would otherwise serialise read - wait - write per sample)
+                uint2 l[SPG];
 #pragma unroll
                 for (int i = 0; i < SPG; i++) {
                     if (MULTI) {
@@ -1304,13 +1307,16 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                         }
                     }
                     const int pos = DTYPE == 2 ? (i & 1) : (i & 3);
-                    const uint2 l = lut[32 * pos + (int)(phi >> 59)];
+                    l[i] = lut[32 * pos + (int)(phi >> 59)];
+                    phi += dfx;
+                }
+#pragma unroll
+                for (int i = 0; i < SPG; i++) {
                     const unsigned wd = w[DTYPE == 2 ? i >> 1 : i >> 2];
-                    aI = __builtin_amdgcn_sdot4((int)wd, (int)l.x, aI, false);
-                    aQ = __builtin_amdgcn_sdot4((int)wd, (int)l.y, aQ, false);
+                    aI = __builtin_amdgcn_sdot4((int)wd, (int)l[i].x, aI, false);
+                    aQ = __builtin_amdgcn_sdot4((int)wd, (int)l[i].y, aQ, false);
                     const int p = it * SPG + i + 1;
                     if (p < LSP) loc[tl * LPAD + p] = make_int2(aI, aQ);
-                    phi += dfx;
                 }
             }
         };
