@@ -101,8 +101,6 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
     }
     hipFree(ctx->dnco_overflow); ctx->dnco_overflow = nullptr;
     hipFree(ctx->dring_viol); ctx->dring_viol = nullptr;
-    hipFree(ctx->dwrpos); ctx->dwrpos = nullptr;
-    ctx->wrpos_sent[0] = ctx->wrpos_sent[1] = ~0ull;
     ctx->plan_cap = 0;
 }
 
@@ -601,7 +599,6 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipMemsetAsync(ctx->dnco_overflow, 0, sizeof(int), ctx->stream));
     GC_HIP(hipMalloc((void **)&ctx->dring_viol, sizeof(int)));
     GC_HIP(hipMemsetAsync(ctx->dring_viol, 0, sizeof(int), ctx->stream));
-    GC_HIP(hipMalloc((void **)&ctx->dwrpos, sizeof(uint64_t) * ctx->nch));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
 }
@@ -616,8 +613,8 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     rc = gc_ingest_fence(ctx);
     if (rc) return rc;
     // ---- planner: use the look-ahead plan if it matches, else plan now ----
-    // plan = the sequential NCO chain per channel, expand = the per-unit constants of that plan; both
-    // run on the planner stream into slot buffers, ev_plan[slot] marks them ready
+    // plan = the sequential NCO chain per channel (discovery pass + chain), on the planner stream into the
+    // slot's plan buffer; ev_plan[slot] marks it ready
     hipStream_t ps = ctx->stream2 ? ctx->stream2 : ctx->stream;
     auto plan_into = [&](int s) -> int {
         // the slot's partial sums were last read by the finish of two batches ago: ordering the plan
@@ -632,12 +629,6 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
             GcTimed t(ctx, "trk_plan", ps);
             int r2 = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
                                         ctx->dplan2[s], ctx->nch, nepoch, ctx->dspec);
-            if (r2) return r2;
-        }
-        {
-            GcTimed t(ctx, "trk_expand", ps);
-            int r2 = gc_launch_trk_expand(ps, ctx->dchan, ctx->dplan2[s], ctx->dunit2[s], ctx->dsegs2[s], ctx->dnsamp2[s],
-                                          ctx->nch, nepoch, ctx->drounds2[s], ctx->nseg, ctx->max_n, ctx->dnco_overflow);
             if (r2) return r2;
         }
         if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[s], ps));
@@ -657,16 +648,19 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         if (rc) return rc;
     }
     if (ctx->stream2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_plan[slot], 0));
-    // the planned periods against what the rings hold now
-    if (ctx->wrpos_sent[0] != ctx->ring[0].wrpos || ctx->wrpos_sent[1] != ctx->ring[1].wrpos) {
-        std::vector<uint64_t> wp(ctx->nch);
-        for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
-        GC_HIP(hipMemcpyAsync(ctx->dwrpos, wp.data(), sizeof(uint64_t) * ctx->nch, hipMemcpyHostToDevice, ctx->stream));
-        GC_HIP(hipStreamSynchronize(ctx->stream));      // (wp is a local; only when the write position moved)
-        ctx->wrpos_sent[0] = ctx->ring[0].wrpos;
-        ctx->wrpos_sent[1] = ctx->ring[1].wrpos;
+    // the per-unit constants and NCO tables of the planned periods: on the main stream, in front of the
+    // correlator that reads them (the planner stream carries nothing but the sequential chain)
+    {
+        const int s = slot;
+        GcTimed t(ctx, "trk_expand");
+        int r2 = gc_launch_trk_expand(ctx->stream, ctx->dchan, ctx->dplan2[s], ctx->dunit2[s], ctx->dsegs2[s], ctx->dnsamp2[s],
+                                      ctx->nch, nepoch, ctx->drounds2[s], ctx->nseg, ctx->max_n, ctx->dnco_overflow);
+        if (r2) return r2;
     }
-    rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], ctx->dwrpos, ctx->nch, nepoch, ctx->dring_viol);
+    // the planned periods against what the rings hold now
+    // (the write positions travel as kernel arguments: no copy, no host synchronisation per batch)
+    rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], (const int8_t *)ctx->ring[0].mem, ctx->ring[0].wrpos,
+                                 ctx->ring[1].wrpos, ctx->nch, nepoch, ctx->dring_viol);
     if (rc) return rc;
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;

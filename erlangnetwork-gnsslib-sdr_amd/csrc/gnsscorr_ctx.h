@@ -78,8 +78,6 @@ struct gnsscorr_ctx {
     GcUnitSegs *dsegs2[2] = {nullptr, nullptr};    // [unit]: the unit's carrier / code NCO piece tables
     int *dnco_overflow = nullptr;
     int *dring_viol = nullptr;                     // planned periods outside what the ring holds, since the last fetch
-    uint64_t *dwrpos = nullptr;                    // [nch] write position of each channel's ring at the last run
-    uint64_t wrpos_sent[2] = {~0ull, ~0ull};       // ring write positions dwrpos was built from
     // closed loop (gnsscorr_trk_run_loop): per channel loop state, NCO tables of the period at hand,
     // one log row per period
     gnsscorr_loop_t *dloop = nullptr;              // [nch]

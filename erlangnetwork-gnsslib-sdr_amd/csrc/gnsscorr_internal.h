@@ -143,8 +143,8 @@ int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,
                          double *sumQ, unsigned long long *scratch, int nch, int nepoch, int nseg, int ntap);
 int gc_trk_nseg(int dtype, int max_n);
-int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const uint64_t *wrpos, int nch,
-                            int nepoch, int *viol);
+int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const int8_t *ring0, uint64_t wrpos0,
+                            uint64_t wrpos1, int nch, int nepoch, int *viol);
 int gc_launch_trk_loop(hipStream_t st, const GcChan *chan, GcTrkState *state, gnsscorr_loop_t *loop, const uint64_t *wrpos,
                        double *corrI, double *corrQ, int *nsamp_out, gnsscorr_trklog_t *log, int *ndone, int *nco_overflow,
                        int nch, int nper, int nseg, int dtype, int ntap, int max_n, int smax_max);

@@ -2018,22 +2018,24 @@ int gc_launch_trk_loop(hipStream_t st, const GcChan *chan, GcTrkState *state, gn
 // bufflocnow > buffloc before it tracks a period, ref src/sdrtrk.c:26-30) and not yet overwritten (the
 // reference stops on a buffer overrun, ref src/sdrrcv.c:325-349).  Counts the periods that do not.
 __global__ void trk_ringcheck_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
-                                     const uint64_t *__restrict__ wrpos, int nch, int nepoch, int *__restrict__ viol)
+                                     const int8_t *ring0, uint64_t wrpos0, uint64_t wrpos1, int nch, int nepoch,
+                                     int *__restrict__ viol)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nch * nepoch) return;
     const int ch = i / nepoch;
     const GcTrkPlan p = plan[i];
     if (p.n <= 0) return;
-    const uint64_t wp = wrpos[ch], rl = chan[ch].ringlen;
+    const uint64_t wp = chan[ch].ring == ring0 ? wrpos0 : wrpos1, rl = chan[ch].ringlen;     // (front end 1 or 2)
     if (p.buffloc + (uint64_t)p.n > wp || (wp > rl && p.buffloc < wp - rl)) atomicAdd(viol, 1);
 }
 
-int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const uint64_t *wrpos, int nch,
-                            int nepoch, int *viol)
+int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const int8_t *ring0, uint64_t wrpos0,
+                            uint64_t wrpos1, int nch, int nepoch, int *viol)
 {
     const int total = nch * nepoch;
-    hipLaunchKernelGGL(trk_ringcheck_kernel, dim3((total + 255) / 256), dim3(256), 0, st, chan, plan, wrpos, nch, nepoch, viol);
+    hipLaunchKernelGGL(trk_ringcheck_kernel, dim3((total + 255) / 256), dim3(256), 0, st, chan, plan, ring0, wrpos0, wrpos1,
+                       nch, nepoch, viol);
     GC_HIP(hipGetLastError());
     return 0;
 }
