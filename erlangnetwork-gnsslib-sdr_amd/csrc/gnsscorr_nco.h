@@ -1280,7 +1280,7 @@ GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc
 // step holds.
 #define GC_CLAIM_ROW   20           // ints per (channel, period) row of either NCO
 #define GC_CLAIM_LIT   5            // code: literal additions after the first wrap, at most (as gc_code_period_body)
-#define GC_CLAIM_TAIL  16           // code: literal additions after the second wrap, at most
+#define GC_CLAIM_TAIL  15           // code: literal additions after the second wrap, at most
 #define GC_CLAIM_CLIT  8            // carrier: literal additions next to zero, at most (as gc_carrier_period)
 #define GC_CLAIM_CSEG  13           // carrier: binade segments, at most
 #define GC_CLAIM_PREM  12           // carrier: subtractions of DPI in the remainder loop, at most (12: up to ~11 kHz at 1 ms)
@@ -1308,6 +1308,31 @@ GC_HD int gc_expo(double x) { return (int)((gc_d2u(x) >> 52) & 0x7FF); }
 #else
 #define GC_PIN_V(x) do { } while (0)
 #endif
+// The evaluating form runs with every lane of a wavefront on the same period: a count it indexes registers with
+// is the same in all lanes, and saying so (readfirstlane) lets the index go through the scalar unit.  (Never
+// in the discovering form, whose lanes are different periods.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define GC_UNIFORM_INT(x) (x)
+#endif
+// a[idx] for an index that is the same in every lane: on the device through a vector value (indexed register
+// move), never through memory
+template <int N>
+GC_HD double gc_pick(const double (&a)[N], int idx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double gc_vec16 __attribute__((ext_vector_type(16)));
+    static_assert(N <= 16, "gc_pick: at most 16 values");
+    gc_vec16 v;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = a[i < N ? i : N - 1];
+    return v[idx & 15];
+#else
+    return a[idx];
+#endif
+}
+
 template <int ITOP>
 struct GcCodeStepC {
     double d[ITOP + 1], top[ITOP + 1], pre[ITOP + 1];      // step, top of the binade (the code length for ITOP), the tie binade's own addition (ci or 0)
@@ -1377,13 +1402,21 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
     } else {
         nl = cl.nl;
     }
+    {
+        // all GC_CLAIM_LIT sums, then the claimed one: the values rise, so "the last addition started below the
+        // table and ended in it" covers the ones before it
+        double ys[GC_CLAIM_LIT + 1];
+        ys[0] = y;
 #pragma unroll
-    for (int k = 0; k < GC_CLAIM_LIT; k++) {
-        const bool lit = k < nl;
-        ok = ok && (!lit || y < b0);
-        y = y + (lit ? ci : 0.0);
+        for (int k = 0; k < GC_CLAIM_LIT; k++) ys[k + 1] = ys[k] + ci;
+        const int nlu = DISCOVER ? nl : GC_UNIFORM_INT(nl);
+        const bool inr = nlu >= 0 && nlu <= GC_CLAIM_LIT;
+        const int ix = inr ? nlu : 0;
+        const double yprev = gc_pick(ys, ix > 0 ? ix - 1 : 0);
+        y = gc_pick(ys, ix);
+        ok = ok && inr && (ix == 0 || yprev < b0);
     }
-    ok = ok && y >= b0 && nl >= 0 && q + 1 + nl < nt - 2;
+    ok = ok && y >= b0 && q + 1 + nl < nt - 2;
     const int i0 = gc_expo(y) - (C.ex_top - ITOP);
     if (DISCOVER) cl.i0 = i0;
     ok = ok && i0 == cl.i0 && i0 >= 0 && i0 <= 1;
@@ -1400,6 +1433,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
             j += active ? (C.pre[i] != 0.0 ? 1 : 0) + dm + 1 : 0;
         } else {
             dm = cl.dm[i];
+            GC_PIN_V(dm);
         }
         const double yl = fma((double)dm, C.d[i], y1);
         const double yn = yl + ci;
@@ -1418,8 +1452,14 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
     y = y - dlen;
     const int t = nt - j;
     ok = ok && t >= 1 && t <= TMAX;
+    {
+        double ys[TMAX + 1];
+        ys[0] = y;
 #pragma unroll
-    for (int k = 0; k < TMAX; k++) y = y + (k < t ? ci : 0.0);
+        for (int k = 0; k < TMAX; k++) ys[k + 1] = ys[k] + ci;
+        const int tu = DISCOVER ? t : GC_UNIFORM_INT(t);
+        y = gc_pick(ys, (tu >= 1 && tu <= TMAX) ? tu : 0);
+    }
     *remcode_out = y - C.smaxci;
     if (DISCOVER) cl.tag = ok ? 1 : 0;
     return ok;
@@ -1555,7 +1595,8 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
 #pragma unroll
         for (int p = 0; p < GC_CLAIM_CWIN; p++) {
             const bool active = (p >= p0) & (p <= plast), last = p == plast;
-            const int dm = cl.dm[p];
+            int dm = cl.dm[p];
+            if (!DISCOVER) GC_PIN_V(dm);            // (stays in its vector register: the chain is short of scalar ones)
             const double x1 = x + C.pre[p];
             const double xl = fma((double)dm, C.d[p], x1);
             const double xn = xl + s;
@@ -1576,16 +1617,20 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
     } else {
         kp = cl.kprem;
     }
-    ok = ok & (kp >= 0) & (kp <= GC_CLAIM_PREM);
-    double pprev = p;
+    {
+        // all GC_CLAIM_PREM differences, then the claimed one (the values fall: if the last subtraction was
+        // called for, so were the ones before it)
+        double ps[GC_CLAIM_PREM + 1];
+        ps[0] = p;
 #pragma unroll
-    for (int k = 0; k < GC_CLAIM_PREM; k++) {
-        const bool sub = k >= GC_CLAIM_PREM - kp;
-        pprev = p;
-        p = p - (sub ? GC_NCO_DPI : 0.0);
+        for (int k = 0; k < GC_CLAIM_PREM; k++) ps[k + 1] = ps[k] - GC_NCO_DPI;
+        const int ku = DISCOVER ? kp : GC_UNIFORM_INT(kp);
+        const bool inr = ku >= 0 && ku <= GC_CLAIM_PREM;
+        const int ix = inr ? ku : 0;
+        const double pprev = gc_pick(ps, ix > 0 ? ix - 1 : 0);
+        p = gc_pick(ps, ix);
+        ok = ok & inr & ((ix == 0) | (pprev > GC_NCO_DPI)) & !(p > GC_NCO_DPI);
     }
-    // (the values fall: if the last subtraction was called for, so were the ones before it)
-    ok = ok & ((kp == 0) | (pprev > GC_NCO_DPI)) & !(p > GC_NCO_DPI);
     *remcarr_out = p;
     if (DISCOVER && !ok) cl.tag = 0;
     return ok;

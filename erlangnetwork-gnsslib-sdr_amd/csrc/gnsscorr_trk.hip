@@ -582,17 +582,17 @@ __global__ __launch_bounds__(128) void trk_plan2_kernel(const GcChan *__restrict
     const int4 *src = reinterpret_cast<const int4 *>(claims_code) + (size_t)ch * nepoch * RQ;
     switch (cls) {
     case 0:  plan2_code_wave<7, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 1:  plan2_code_wave<7, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 1:  plan2_code_wave<7, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 2:  plan2_code_wave<8, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 3:  plan2_code_wave<8, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 3:  plan2_code_wave<8, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 4:  plan2_code_wave<9, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 5:  plan2_code_wave<9, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 5:  plan2_code_wave<9, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 6:  plan2_code_wave<10, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 7:  plan2_code_wave<10, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 7:  plan2_code_wave<10, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 8:  plan2_code_wave<11, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 9:  plan2_code_wave<11, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 9:  plan2_code_wave<11, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 10: plan2_code_wave<12, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    default: plan2_code_wave<12, 16>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    default: plan2_code_wave<12, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     }
 }
 
