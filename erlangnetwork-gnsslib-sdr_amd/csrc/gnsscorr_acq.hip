@@ -63,6 +63,7 @@ struct GcAcqWork {
     size_t  X_elems = 0;
     float2 *C = nullptr;        // [ch][2][16384]
     GcAcqRow *rows = nullptr;   // [ch][iter][bin]
+    int *arrive = nullptr;      // [ch][iter] workgroups done with the iteration, then [ch] "acquired" flags
     int *iters = nullptr;       // [ch] iteration limit for acq_corr
     gnsscorr_acqres_t *res = nullptr;   // [ch]
     double *P = nullptr;        // one channel's power array (on demand)
@@ -371,20 +372,22 @@ template <int NT>
 __global__ __launch_bounds__(NT) void acq_corr_kernel(
     const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32p,
     const float2 *__restrict__ X, const float2 *__restrict__ C, const int *__restrict__ iters,
-    GcAcqRow *__restrict__ rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg, int nchg)
+    GcAcqRow *rows, double *__restrict__ Pout, int pout_ch, int maxfreq, int maxintg, int nchg,
+    int *arrive, int *done)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     double *sd = reinterpret_cast<double *>(smem + GC_FFT_LDS);       // 32 doubles
     int *si = reinterpret_cast<int *>(smem + GC_FFT_LDS + 256);       // 16 ints
-    // Workgroup order (speed only): blocks b, b+8, b+16, ... tend to share an XCD, so each XCD walks
-    // the Doppler bins of one channel before the next channel: the channel's code spectrum (256 KB)
-    // stays in that XCD's L2 for all its bins and iterations, and the forward spectra -- read once per
-    // (bin, channel) either way -- stream from the Infinity Cache, which holds all of them (186 MB).
+    // Workgroup order: the Doppler bins of one channel are consecutive blocks, so they run side by side (71
+    // bins on 256 CUs: three to four channels at a time) and reach the end of each iteration together --
+    // what lets the channel stop at the iteration that acquires it (below).  The channel's code spectrum
+    // (256 KB) is then held by every XCD's L2, the forward spectra stream from the Infinity Cache, which
+    // holds all of them (186 MB).  (Pout: one channel's power array, blocks = its bins.)
     const int tid0 = threadIdx.x;
     const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int bin = Pout ? qq * 8 + slot : qq % maxfreq;
-    const int ch = Pout ? pout_ch : (qq / maxfreq) * 8 + slot;
+    const int bin = Pout ? qq * 8 + slot : (int)(blockIdx.x % (unsigned)maxfreq);
+    const int ch = Pout ? pout_ch : (int)(blockIdx.x / (unsigned)maxfreq);
     if (bin >= maxfreq || (!Pout && ch >= nchg)) return;
     const GcChan &c = chan[ch];
     if (bin >= c.nfreq) return;
@@ -497,7 +500,41 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
             r.rowmax = m.v; r.sum_out = so; r.max_out = mo; r.argmax = m.k; r.pad = 0;
             rows[((size_t)ch * maxintg + it) * maxfreq + bin] = r;
         }
+        // The reference stops a channel at the first iteration whose peak ratio passes the threshold
+        // (ref src/sdracq.c:39-42); so does this: the workgroup that finishes an iteration of its channel
+        // last takes the decision acq_final will take from the same rows, and the channel's workgroups
+        // leave at the next iteration boundary they reach after it.  (Iterations past the acquiring one
+        // are never looked at: what they would have written is not missed.)
+        if (arrive && tid < 64) {
+            int last = 0;
+            if (tid == 0) {
+                __threadfence();
+                last = atomicAdd(&arrive[ch * maxintg + it], 1) == c.nfreq - 1;
+            }
+            last = __shfl(last, 0);
+            if (last) {
+                __threadfence();
+                const GcAcqRow *row = rows + ((size_t)ch * maxintg + it) * maxfreq;
+                double bv = -1.0;
+                int bi = 0x7fffffff;
+                for (int b = tid; b < c.nfreq; b += 64) {
+                    const double v = row[b].rowmax;
+                    if (v > bv) { bv = v; bi = b; }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double ov = __shfl_xor(bv, d);
+                    const int oi = __shfl_xor(bi, d);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                const GcAcqRow w = row[bi];
+                if (tid == 0 && w.rowmax / w.max_out > 3.0)                 // ACQTH, as acq_final
+                    __hip_atomic_store(&done[ch], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) si[15] = __hip_atomic_load(&done[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();      // LDS image and reduction scratch are reused next iteration
+        if (arrive && si[15]) break;
     }
     if (Pout) {
 #pragma unroll
@@ -796,7 +833,7 @@ void gc_acq_free(gnsscorr_ctx *ctx)
     GcAcqWork *w = ctx->acq;
     if (!w) return;
     hipFree(w->tw16k); hipFree(w->tw32k); hipFree(w->tw32p); hipFree(w->tw64p1); hipFree(w->tw64p3);
-    hipFree(w->X); hipFree(w->C); hipFree(w->rows);
+    hipFree(w->X); hipFree(w->C); hipFree(w->rows); hipFree(w->arrive);
     hipFree(w->iters); hipFree(w->res); hipFree(w->P);
     hipFree(w->d_grid_chan); hipFree(w->d_grid_wrpos); hipFree(w->car); hipFree(w->car_overflow);
     delete w;
@@ -855,6 +892,7 @@ static int acq_prepare(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&w->X, sizeof(float2) * w->X_elems));
     GC_HIP(hipMalloc((void **)&w->C, sizeof(float2) * (size_t)nch * w->L));
     GC_HIP(hipMalloc((void **)&w->rows, sizeof(GcAcqRow) * (size_t)nch * w->maxintg * w->maxfreq));
+    GC_HIP(hipMalloc((void **)&w->arrive, sizeof(int) * ((size_t)nch * w->maxintg + nch)));
     GC_HIP(hipMalloc((void **)&w->iters, sizeof(int) * nch));
     GC_HIP(hipMalloc((void **)&w->res, sizeof(gnsscorr_acqres_t) * nch));
     GC_HIP(hipMalloc((void **)&w->d_grid_chan, sizeof(int) * w->ngrid));
@@ -920,6 +958,8 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     GC_HIP(hipGetLastError());
     hipLaunchKernelGGL(fill_int_kernel, dim3((ctx->nch + 63) / 64), dim3(64), 0, ctx->stream, w->iters,
                        ctx->dchan, ctx->nch);
+    // arrival counters per (channel, iteration) and the channels' "acquired" flags
+    GC_HIP(hipMemsetAsync(w->arrive, 0, sizeof(int) * ((size_t)ctx->nch * w->maxintg + ctx->nch), ctx->stream));
     {
         GcTimed t(ctx, "acq_corr");
         static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
@@ -928,13 +968,13 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->tw64p1, w->tw64p3, w->X, w->C, w->iters,
                                w->rows, (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
         else if (nt == 1024)
-            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(1024), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(ctx->nch * w->maxfreq), dim3(1024), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
-                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
+                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch, w->arrive, w->arrive + (size_t)ctx->nch * w->maxintg);
         else
-            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(512), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(ctx->nch * w->maxfreq), dim3(512), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
-                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
+                               (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch, w->arrive, w->arrive + (size_t)ctx->nch * w->maxintg);
     }
     GC_HIP(hipGetLastError());
     {
@@ -1012,7 +1052,7 @@ extern "C" int gnsscorr_acq_power(gnsscorr_ctx *ctx, int ch, double *power)
     else
         hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(8 * ((c.nfreq + 7) / 8)), dim3(512), GC_FFT_LDS + 512,
                            ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows, w->P, ch,
-                           w->maxfreq, w->maxintg, 1);
+                           w->maxfreq, w->maxintg, 1, (int *)nullptr, (int *)nullptr);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(power, w->P, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
