@@ -386,7 +386,9 @@ extern "C" int gnsscorr_ring_commit(gnsscorr_ctx *ctx, int ftype, uint64_t nsamp
 extern "C" uint64_t gnsscorr_ring_wrpos(gnsscorr_ctx *ctx, int ftype)
 {
     GcRing *r = ring_of(ctx, ftype);
-    return r ? r->wrpos : 0;
+    if (!r) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    return r->wrpos;
 }
 
 extern "C" void *gnsscorr_ring_devptr(gnsscorr_ctx *ctx, int ftype)
@@ -659,8 +661,14 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     }
     // the planned periods against what the rings hold now
     // (the write positions travel as kernel arguments: no copy, no host synchronisation per batch)
-    rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], (const int8_t *)ctx->ring[0].mem, ctx->ring[0].wrpos,
-                                 ctx->ring[1].wrpos, ctx->nch, nepoch, ctx->dring_viol);
+    uint64_t wr0, wr1;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);       // (a grabber thread may be pushing)
+        wr0 = ctx->ring[0].wrpos;
+        wr1 = ctx->ring[1].wrpos;
+    }
+    rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], (const int8_t *)ctx->ring[0].mem, wr0, wr1, ctx->nch,
+                                 nepoch, ctx->dring_viol);
     if (rc) return rc;
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
@@ -776,7 +784,10 @@ extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
     GC_HIP(hipMemsetAsync(ctx->dnsamp2[0], 0, sizeof(int) * units, ctx->stream));
     // write position of each channel's ring (ref src/sdrtrk.c:26-28: fendbuffsize*buffcnt)
     std::vector<uint64_t> wp(ctx->nch);
-    for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
+    }
     uint64_t *dwp = reinterpret_cast<uint64_t *>(ctx->dloopdone + ctx->nch + (ctx->nch & 1));
     GC_HIP(hipMemcpyAsync(dwp, wp.data(), sizeof(uint64_t) * ctx->nch, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));          // (wp is a local)
