@@ -1300,6 +1300,7 @@ struct GcCarClaims {                // GC_CLAIM_ROW ints
 };
 
 GC_HD int gc_expo(double x) { return (int)((gc_d2u(x) >> 52) & 0x7FF); }
+GC_HD uint32_t gc_hi32(double x) { return (uint32_t)(gc_d2u(x) >> 32); }
 
 // per-channel constants of the code step, as the evaluation wants them: every one a plain value (on the device
 // they are pinned to vector registers, GC_PIN_V: the chain's wavefront has few scalar registers to spare)
@@ -1335,9 +1336,9 @@ GC_HD double gc_pick(const double (&a)[N], int idx)
 
 template <int ITOP>
 struct GcCodeStepC {
-    double d[ITOP + 1], top[ITOP + 1], pre[ITOP + 1];      // step, top of the binade (the code length for ITOP), the tie binade's own addition (ci or 0)
+    double d[ITOP + 1], pre[ITOP + 1];                     // step, the tie binade's own addition (ci or 0)
     double ci, dlen, b0, smaxci;
-    int    ex_top;                                          // biased exponent the start value must have
+    int    ex_top;                                          // biased exponent the start value must have (binade ITOP's)
 };
 
 template <int ITOP>
@@ -1351,10 +1352,8 @@ GC_HD void gc_code_stepc_init(GcCodeStepC<ITOP> &C, const GcCodePlan &P)
 #pragma unroll
     for (int i = 0; i <= ITOP; i++) {
         C.d[i] = P.f.d[i];
-        C.top[i] = i == ITOP ? P.dlen : gc_u2d((uint64_t)(P.f.ex0 + i + 1) << 52);
         C.pre[i] = i == P.it ? P.f.s : 0.0;
         GC_PIN_V(C.d[i]);
-        GC_PIN_V(C.top[i]);
         GC_PIN_V(C.pre[i]);
     }
     GC_PIN_V(C.ci);
@@ -1437,7 +1436,16 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
         }
         const double yl = fma((double)dm, C.d[i], y1);
         const double yn = yl + ci;
-        ok = ok && (!active || (dm >= 0 && yl < C.top[i] && yn >= C.top[i]));
+        // last value of the segment below the top of its binade, the next one at or above it: for the table's
+        // binades (tops are powers of two, the values positive) a comparison of the exponent fields
+        bool in;
+        if (i == ITOP) {
+            in = yl < dlen && yn >= dlen;
+        } else {
+            const uint32_t ktop = (uint32_t)(C.ex_top - ITOP + i + 1) << 20;
+            in = gc_hi32(yl) < ktop && gc_hi32(yn) >= ktop;
+        }
+        ok = ok && (!active || (dm >= 0 && in));
         y = active ? yn : y;
     }
     if (DISCOVER) {
@@ -1501,7 +1509,7 @@ GC_HD bool gc_code_claims(const GcCodePlan &P, double remcode, int nt, GcCodeCla
 // walkers.
 #define GC_CLAIM_CWIN 8
 struct GcCarStepC {
-    double d[GC_CLAIM_CWIN], top[GC_CLAIM_CWIN], pre[GC_CLAIM_CWIN];   // step, top of the binade, the tie binade's own addition (s or 0)
+    double d[GC_CLAIM_CWIN], pre[GC_CLAIM_CWIN];   // step, the tie binade's own addition (s or 0)
     double s;
     int    ilo, ex0;                // first binade of the window; biased exponent of table binade 0
 };
@@ -1523,17 +1531,14 @@ GC_HD void gc_car_stepc_init(GcCarStepC &C, const GcCarPlan &P, int nmax)
 #pragma unroll
     for (int p = 0; p < GC_CLAIM_CWIN; p++) {
         C.d[p] = 0.0;
-        C.top[p] = 0.0;
         C.pre[p] = 0.0;
 #pragma unroll
         for (int i = 0; i < GC_NB; i++) {           // (static indices into the table)
             if (i != C.ilo + p) continue;
             C.d[p] = f.d[i];
-            C.top[p] = gc_u2d((uint64_t)(f.ex0 + i + 1) << 52);
             C.pre[p] = ((f.tie >> i) & 1) ? f.s : 0.0;
         }
         GC_PIN_V(C.d[p]);
-        GC_PIN_V(C.top[p]);
         GC_PIN_V(C.pre[p]);
     }
     GC_PIN_V(C.s);
@@ -1600,7 +1605,10 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
             const double x1 = x + C.pre[p];
             const double xl = fma((double)dm, C.d[p], x1);
             const double xn = xl + s;
-            ok = ok & ((int)!active | ((int)(dm >= 0) & (int)(fabs(xl) < C.top[p]) & ((int)last | (int)(fabs(xn) >= C.top[p]))));
+            // (magnitudes against the top of the binade, a power of two: exponent fields)
+            const uint32_t ktop = (uint32_t)(C.ex0 + C.ilo + p + 1) << 20;
+            const uint32_t hl = gc_hi32(xl) & 0x7FFFFFFFu, hn = gc_hi32(xn) & 0x7FFFFFFFu;
+            ok = ok & ((int)!active | ((int)(dm >= 0) & (int)(hl < ktop) & ((int)last | (int)(hn >= ktop))));
             x = active ? xn : x;
         }
     }

@@ -352,6 +352,10 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
     int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[0];
     constexpr int RQ = GC_CLAIM_ROW / 4;
+    // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
+    // until they are used, so the next period's row really is in flight during this period's step)
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
     unsigned tally[3] = {0, 0, 0};
 #ifdef GC_PLAN_PROF
     unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
@@ -385,7 +389,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
         int k_n = 0;
         GcCodeClaims nx;
         {
-            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]);
+            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + vzero;
             int4 v[RQ];
 #pragma unroll
             for (int q = 0; q < RQ; q++) v[q] = r[q];
@@ -395,7 +399,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
             GC_PP(0);
             GcCodeClaims cl = nx;
             if (e + 1 < e1) {                       // the next period's claims, in flight during this one
-                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ;
+                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
 #pragma unroll
                 for (int q = 0; q < RQ; q++) v[q] = r[q];
@@ -474,6 +478,10 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
     gc_car_stepc_init(CK, PK, c.nsamp + 16);
     int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[1];
     constexpr int RQ = GC_CLAIM_ROW / 4;
+    // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
+    // until they are used, so the next period's row really is in flight during this period's step)
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
     unsigned tally[3] = {0, 0, 0};
 #ifdef GC_PLAN_PROF
     unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
@@ -508,7 +516,7 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
         GcCarClaims nx;
         int nn;
         {
-            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]);
+            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + vzero;
             int4 v[RQ];
 #pragma unroll
             for (int q = 0; q < RQ; q++) v[q] = r[q];
@@ -521,7 +529,7 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
             GcCarClaims cl = nx;
             const int n = nn;
             if (e + 1 < e1) {
-                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ;
+                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
 #pragma unroll
                 for (int q = 0; q < RQ; q++) v[q] = r[q];
