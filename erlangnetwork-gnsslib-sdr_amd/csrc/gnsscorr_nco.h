@@ -1372,7 +1372,9 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
     // ---- start value (ref src/sdrcmn.c:613-614) and head, as gc_code_period_body
     const double cs = remcode - C.smaxci;
     const double c0 = cs < 0.0 ? cs + dlen : cs;
-    ok = ok && cs >= -dlen && cs < dlen && gc_expo(c0) == C.ex_top && c0 < dlen;
+    // (c0 positive, in the code length's binade and below the code length: with it -dlen <= cs < dlen, the range
+    // in which the reference's floor(cs/dlen) is -1 or 0)
+    ok = ok && (int)(gc_hi32(c0) >> 20) == C.ex_top && c0 < dlen;
     int q;
     if (DISCOVER) {
         const double R = P.limtop - c0;
@@ -1387,7 +1389,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
     const double dq = (double)q;
     const double yq = fma(dq, dtop, c0);            // last sample below the code length ...
     double y = fma(dq + 1.0, dtop, c0);             // ... and the first at or above it
-    ok = ok && q >= 0 && q < nt - 2 && yq < dlen && y >= dlen;
+    ok = ok && q < nt - 2 && yq < dlen && y >= dlen;         // (a negative q fails the last comparison)
     y = y - dlen;
     // ---- next to zero: the reference's own additions up to the table
     const double b0 = C.b0;
@@ -1421,6 +1423,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
     ok = ok && i0 == cl.i0 && i0 >= 0 && i0 <= 1;
     // ---- climb: one segment per table binade (only binade 0 can be skipped: i0 is 0 or 1)
     int j = q + 1 + nl;
+    int dmor = 0;                                   // (no claimed count negative: one test for all of them)
 #pragma unroll
     for (int i = 0; i <= ITOP; i++) {
         const bool active = i > 0 || i0 == 0;
@@ -1445,9 +1448,11 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
             const uint32_t ktop = (uint32_t)(C.ex_top - ITOP + i + 1) << 20;
             in = gc_hi32(yl) < ktop && gc_hi32(yn) >= ktop;
         }
-        ok = ok && (!active || (dm >= 0 && in));
+        ok = ok && (!active || in);
+        dmor |= dm;
         y = active ? yn : y;
     }
+    ok = ok && dmor >= 0;
     if (DISCOVER) {
 #pragma unroll
         for (int i = ITOP + 1; i < 13; i++) cl.dm[i] = 0;
@@ -1597,6 +1602,7 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
         }
         ok = ok & (i0 == cl.i0) & (cl.nseg >= 1) & (p0 + cl.nseg <= GC_CLAIM_CWIN) & (cl.nl == n);
         const int plast = p0 + cl.nseg - 1;
+        int dmor = 0;                               // (no claimed count negative: one test for all of them)
 #pragma unroll
         for (int p = 0; p < GC_CLAIM_CWIN; p++) {
             const bool active = (p >= p0) & (p <= plast), last = p == plast;
@@ -1608,9 +1614,11 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
             // (magnitudes against the top of the binade, a power of two: exponent fields)
             const uint32_t ktop = (uint32_t)(C.ex0 + C.ilo + p + 1) << 20;
             const uint32_t hl = gc_hi32(xl) & 0x7FFFFFFFu, hn = gc_hi32(xn) & 0x7FFFFFFFu;
-            ok = ok & ((int)!active | ((int)(dm >= 0) & (int)(hl < ktop) & ((int)last | (int)(hn >= ktop))));
+            ok = ok & ((int)!active | ((int)(hl < ktop) & ((int)last | (int)(hn >= ktop))));
+            dmor |= dm;
             x = active ? xn : x;
         }
+        ok = ok & (dmor >= 0);
     }
     // ---- phase remainder (ref :666-668): the reference's own subtractions, the last one in the last position
     double p = x * GC_NCO_DPI * (1.0 / GC_NCO_CDIV);

@@ -281,6 +281,30 @@ __device__ __forceinline__ void plan2_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// claims rows as the kernels move them (five 16-byte quads) -> fields
+__device__ __forceinline__ GcCodeClaims plan2_code_row(const int4 (&v)[GC_CLAIM_ROW / 4])
+{
+    GcCodeClaims c;
+    c.tag = v[0].x; c.i0 = v[0].y; c.q = v[0].z; c.nl = v[0].w;
+    c.jsum = v[1].x; c.dm[0] = v[1].y; c.dm[1] = v[1].z; c.dm[2] = v[1].w;
+    c.dm[3] = v[2].x; c.dm[4] = v[2].y; c.dm[5] = v[2].z; c.dm[6] = v[2].w;
+    c.dm[7] = v[3].x; c.dm[8] = v[3].y; c.dm[9] = v[3].z; c.dm[10] = v[3].w;
+    c.dm[11] = v[4].x; c.dm[12] = v[4].y; c.pad[0] = 0; c.pad[1] = 0;
+    return c;
+}
+__device__ __forceinline__ GcCarClaims plan2_car_row(const int4 (&v)[GC_CLAIM_ROW / 4])
+{
+    GcCarClaims c;
+    c.tag = v[0].x; c.nl = v[0].y; c.i0 = v[0].z; c.nseg = v[0].w;
+    c.kprem = v[1].x; c.dm[0] = v[1].y; c.dm[1] = v[1].z; c.dm[2] = v[1].w;
+    c.dm[3] = v[2].x; c.dm[4] = v[2].y; c.dm[5] = v[2].z; c.dm[6] = v[2].w;
+    c.dm[7] = v[3].x; c.dm[8] = v[3].y; c.dm[9] = v[3].z; c.dm[10] = v[3].w;
+    c.dm[11] = v[4].x; c.dm[12] = v[4].y; c.pad[0] = 0; c.pad[1] = 0;
+    return c;
+}
+static_assert(sizeof(GcCodeClaims) == GC_CLAIM_ROW * 4 && sizeof(GcCarClaims) == GC_CLAIM_ROW * 4, "claims rows are GC_CLAIM_ROW ints");
+static_assert(offsetof(GcCodeClaims, dm) == 20 && offsetof(GcCarClaims, dm) == 20, "claims layout");
+
 // A period whose claims did not hold (a few in ten thousand): the certified step, then the walkers, with the
 // tables they need built here -- out of line, so that the chain's loop carries none of it.
 // returns 1: certified step, 2: walkers
@@ -393,7 +417,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
             int4 v[RQ];
 #pragma unroll
             for (int q = 0; q < RQ; q++) v[q] = r[q];
-            memcpy(&nx, v, sizeof(nx));
+            nx = plan2_code_row(v);
         }
         for (int e = e0; e < e1; e++) {
             GC_PP(0);
@@ -403,10 +427,11 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
                 int4 v[RQ];
 #pragma unroll
                 for (int q = 0; q < RQ; q++) v[q] = r[q];
-                memcpy(&nx, v, sizeof(nx));
+                nx = plan2_code_row(v);
             }
             const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
-            const double qn = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
+            double qn = gc_div_y(num, spc, yspc);
+            if (__builtin_expect(!fastdiv, 0)) qn = __ddiv_rn(num, spc);
             const int n = (qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0;
             const bool mine = lane == e - e0;
             k_buff = mine ? s.buffloc : k_buff;
@@ -520,7 +545,7 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
             int4 v[RQ];
 #pragma unroll
             for (int q = 0; q < RQ; q++) v[q] = r[q];
-            memcpy(&nx, v, sizeof(nx));
+            nx = plan2_car_row(v);
             nn = g_plan2.nsh[e0];
         }
         GC_PP(4);
@@ -533,7 +558,7 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
                 int4 v[RQ];
 #pragma unroll
                 for (int q = 0; q < RQ; q++) v[q] = r[q];
-                memcpy(&nx, v, sizeof(nx));
+                nx = plan2_car_row(v);
                 nn = g_plan2.nsh[e + 1];
             }
             const bool mine = lane == e - e0;
