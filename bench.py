@@ -260,7 +260,9 @@ def main():
         step(i)
     se.wait()
     barrier()
-    eng.timing(not os.environ.get("BENCH_NOTIMING"))      # (debug) per-kernel HIP events off
+    # HIP events around the correlator launches only (roofline.launch_ms); the other kernels of the step are
+    # timed in a short pass after the timed region
+    eng.timing(0 if os.environ.get("BENCH_NOTIMING") else 2)
     eng.timing_reset()
     log(f"tracking leg: {args.steps} steps x {args.inner} launches x {E} periods")
     t0 = time.perf_counter()
@@ -287,6 +289,14 @@ def main():
             log("planner clocks/period, channel 0: code [rows+n, step, rest, block] carrier [wait, rows, -, step]:",
                 [round(float(v) / nper, 1) for v in pp[:8]])
     k_ms, k_n = eng.timing_read("trk_corr")
+    # per-kernel times of the whole step: two more steps, every kernel bracketed by events (not part of `value`)
+    eng.timing_reset()
+    eng.timing(1)
+    for i in range(2):
+        step(i)
+    se.wait()
+    barrier()
+    eng.timing(False)
     p_ms, p_n = eng.timing_read("trk_plan")
     s_ms, s_n = eng.timing_read("trk_finish")
     dt_max = dt

@@ -900,7 +900,7 @@ static void drain_timers(gnsscorr_ctx *ctx)
 extern "C" int gnsscorr_timing_enable(gnsscorr_ctx *ctx, int on)
 {
     if (!ctx) return gc_fail(GNSSCORR_EINVAL, "null context");
-    ctx->timing = on != 0;
+    ctx->timing = on == 2 ? 2 : (on != 0);
     return GNSSCORR_OK;
 }
 

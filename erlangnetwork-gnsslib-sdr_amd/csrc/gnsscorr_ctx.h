@@ -7,6 +7,7 @@
 #include <utility>
 #include <vector>
 
+#include <cstring>
 #include "gnsscorr_internal.h"
 
 struct GcRing {
@@ -102,7 +103,7 @@ struct gnsscorr_ctx {
     GcAcqWork *acq = nullptr;
 
     // timing
-    bool timing = false;
+    int timing = 0;                                // 0: off, 1: every kernel, 2: only the two correlator kernels (trk_corr, acq_corr)
     std::map<std::string, GcTimer> timers;
 };
 
@@ -115,6 +116,7 @@ struct GcTimed {
     GcTimed(gnsscorr_ctx *c, const char *n, hipStream_t s = nullptr) : ctx(c), name(n), st(s ? s : c->stream)
     {
         if (!ctx->timing) return;
+        if (ctx->timing == 2 && strcmp(n, "trk_corr") != 0 && strcmp(n, "acq_corr") != 0) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         hipEventRecord(a, st);
     }

@@ -237,8 +237,10 @@ int  gnsscorr_pspec(gnsscorr_ctx *ctx, const float *cpx, int n, int flagsum,
                     double *pspec);
 
 /* per-kernel launch timing: enable, run, then read the accumulated HIP-event
- * time of the named kernel ("trk_corr", "trk_plan", "acq_fwd", "acq_corr",
- * "acq_code", "acq_final") */
+ * time of the named kernel ("trk_corr", "trk_plan", "trk_spec", "trk_expand",
+ * "trk_finish", "acq_fwd", "acq_corr", "acq_code", "acq_final").
+ * on = 1: every kernel; on = 2: only the two correlator kernels ("trk_corr",
+ * "acq_corr"), leaving the planner and finish streams free of events; 0: off */
 int  gnsscorr_timing_enable(gnsscorr_ctx *ctx, int on);
 int  gnsscorr_timing_read(gnsscorr_ctx *ctx, const char *kernel,
                           double *total_ms, int *launches);
