@@ -55,6 +55,12 @@ extern "C" int gnsscorr_create(gnsscorr_ctx **out, int device, void *stream)
     }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
     if (!ctx->stream2 || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) ctx->stream3 = nullptr;
+    if (ctx->stream2 && (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&ctx->ev_spec, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming) != hipSuccess)) {
+        if (ctx->stream4) hipStreamDestroy(ctx->stream4);
+        ctx->stream4 = nullptr;
+    }
     for (int i = 0; i < 2 && ctx->stream2; i++) {
         hipEventCreateWithFlags(&ctx->ev_plan[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&ctx->ev_used[i], hipEventDisableTiming);
@@ -84,7 +90,8 @@ static void free_channels(gnsscorr_ctx *ctx)
 static void free_trk_buffers(gnsscorr_ctx *ctx)
 {
     for (int i = 0; i < 2; i++) { hipFree(ctx->dplan2[i]); ctx->dplan2[i] = nullptr; }
-    hipFree(ctx->dspec); ctx->dspec = nullptr;
+    for (int i = 0; i < 2; i++) { hipFree(ctx->dspec2[i]); ctx->dspec2[i] = nullptr; }
+    ctx->spec_ahead_valid = false;
     ctx->ahead_valid = false;
     hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
     hipFree(ctx->dcorrQ); ctx->dcorrQ = nullptr;
@@ -112,6 +119,7 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
+    if (ctx->stream4) hipStreamSynchronize(ctx->stream4);
     gc_acq_free(ctx);
     free_trk_buffers(ctx);
     free_channels(ctx);
@@ -133,6 +141,9 @@ extern "C" void gnsscorr_destroy(gnsscorr_ctx *ctx)
     }
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) hipStreamDestroy(ctx->stream3);
+    if (ctx->stream4) { hipStreamSynchronize(ctx->stream4); hipStreamDestroy(ctx->stream4); }
+    if (ctx->ev_spec) hipEventDestroy(ctx->ev_spec);
+    if (ctx->ev_chain) hipEventDestroy(ctx->ev_chain);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -456,6 +467,9 @@ extern "C" int gnsscorr_set_channels(gnsscorr_ctx *ctx, int nch, const gnsscorr_
                            i, c.ftype, (unsigned long long)r.ringlen, c.nsamp, 32 / c.dtype);
     }
     GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
+    if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream4) GC_HIP(hipStreamSynchronize(ctx->stream4));
     gc_acq_free(ctx);
     free_trk_buffers(ctx);
     free_channels(ctx);
@@ -542,6 +556,7 @@ extern "C" int gnsscorr_trk_set_state(gnsscorr_ctx *ctx, int ch0, int nch, const
     GC_HIP(hipSetDevice(ctx->device));
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
     if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream4) GC_HIP(hipStreamSynchronize(ctx->stream4));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ahead_valid = false;                                         // ... and is dropped
     ctx->state_touched = true;
@@ -558,6 +573,7 @@ extern "C" int gnsscorr_trk_get_state(gnsscorr_ctx *ctx, int ch0, int nch, gnssc
     GC_HIP(hipSetDevice(ctx->device));
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
     if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream4) GC_HIP(hipStreamSynchronize(ctx->stream4));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     GC_HIP(hipMemcpyAsync(st, ctx->dstate2[ctx->state_cur] + ch0, sizeof(GcTrkState) * nch, hipMemcpyDeviceToHost,
                           ctx->stream));
@@ -571,13 +587,15 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     if (units <= ctx->plan_cap) return GNSSCORR_OK;
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));
     if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream4) GC_HIP(hipStreamSynchronize(ctx->stream4));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->ahead_valid) {            // a look-ahead plan advanced the state one batch: roll it back
         ctx->ahead_valid = false;
     }
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
-    GC_HIP(hipMalloc((void **)&ctx->dspec, sizeof(int) * 2 * units * GC_CLAIM_ROW));
+    for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dspec2[i], sizeof(int) * 2 * units * GC_CLAIM_ROW));
+    ctx->spec_ahead_valid = false;
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dsumI, sizeof(double) * ctx->nch * ctx->ntap));
@@ -622,15 +640,40 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         // the slot's partial sums were last read by the finish of two batches ago: ordering the plan
         // behind it lets ev_plan[s] stand for "slot s is free and planned" on the main stream
         if (ctx->stream2 && ctx->fin_pending[s]) GC_HIP(hipStreamWaitEvent(ps, ctx->ev_fin[s], 0));
-        {
+        // claims of this batch: discovered ahead (while the previous batch's chain ran, from that batch's
+        // input state) if nothing has touched the state since, else discovered now from the state itself
+        const GcTrkState *sin = ctx->dstate2[ctx->state_cur];
+        int buf;
+        if (ctx->stream4 && ctx->spec_pending) GC_HIP(hipStreamWaitEvent(ps, ctx->ev_spec, 0));
+        if (ctx->spec_ahead_valid && !ctx->state_touched && ctx->spec_ahead_nepoch == nepoch && ctx->spec_ahead_state == (const void *)sin) {
+            buf = ctx->spec_ahead_buf;
+        } else {
+            buf = 0;
             GcTimed t(ctx, "trk_spec", ps);
-            int r2 = gc_launch_trk_spec(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->nch, nepoch, ctx->dspec);
+            int r2 = gc_launch_trk_spec(ps, ctx->dchan, sin, ctx->nch, nepoch, ctx->dspec2[buf], 0);
             if (r2) return r2;
+        }
+        ctx->spec_ahead_valid = false;
+        ctx->spec_pending = false;
+        if (ctx->stream4) {
+            // the next batch's claims, from the same input state, beside this batch's chain (the other buffer
+            // was last read by the chain in front of this one on the planner stream)
+            GC_HIP(hipEventRecord(ctx->ev_chain, ps));
+            GC_HIP(hipStreamWaitEvent(ctx->stream4, ctx->ev_chain, 0));
+            GcTimed t(ctx, "trk_spec", ctx->stream4);
+            int r2 = gc_launch_trk_spec(ctx->stream4, ctx->dchan, sin, ctx->nch, nepoch, ctx->dspec2[buf ^ 1], nepoch);
+            if (r2) return r2;
+            GC_HIP(hipEventRecord(ctx->ev_spec, ctx->stream4));
+            ctx->spec_pending = true;
+            ctx->spec_ahead_valid = true;
+            ctx->spec_ahead_buf = buf ^ 1;
+            ctx->spec_ahead_nepoch = nepoch;
+            ctx->spec_ahead_state = (const void *)ctx->dstate2[ctx->state_cur ^ 1];
         }
         {
             GcTimed t(ctx, "trk_plan", ps);
-            int r2 = gc_launch_trk_plan(ps, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dstate2[ctx->state_cur ^ 1],
-                                        ctx->dplan2[s], ctx->nch, nepoch, ctx->dspec);
+            int r2 = gc_launch_trk_plan(ps, ctx->dchan, sin, ctx->dstate2[ctx->state_cur ^ 1],
+                                        ctx->dplan2[s], ctx->nch, nepoch, ctx->dspec2[buf]);
             if (r2) return r2;
         }
         if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_plan[s], ps));
@@ -722,6 +765,7 @@ static int loop_quiesce(gnsscorr_ctx *ctx)
 {
     if (ctx->stream2) GC_HIP(hipStreamSynchronize(ctx->stream2));     // a look-ahead plan may be in flight
     if (ctx->stream3) GC_HIP(hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream4) GC_HIP(hipStreamSynchronize(ctx->stream4));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ahead_valid = false;                                         // ... and is dropped
     ctx->state_touched = true;

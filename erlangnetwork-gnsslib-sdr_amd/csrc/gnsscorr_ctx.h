@@ -64,7 +64,15 @@ struct gnsscorr_ctx {
     GcTrkState *dstate2[2] = {nullptr, nullptr};   // ping-pong; cur = index of the committed state
     int state_cur = 0;
     GcTrkPlan *dplan2[2] = {nullptr, nullptr};
-    int *dspec = nullptr;                          // speculated NCO crossings of the batch being planned (planner stream)
+    // claims of the batch being planned (discovery pass -> chain), two buffers: while the chain of one batch reads
+    // its claims the discovery pass of the NEXT batch fills the other one from the same input state, on its own stream
+    int *dspec2[2] = {nullptr, nullptr};
+    hipStream_t stream4 = nullptr;                 // discovery-ahead stream
+    hipEvent_t ev_spec = nullptr, ev_chain = nullptr;
+    bool spec_pending = false;                     // stream4 has work whose end ev_spec marks
+    bool spec_ahead_valid = false;                 // dspec2[spec_ahead_buf] holds claims for the batch that starts at spec_ahead_state
+    int spec_ahead_buf = 0, spec_ahead_nepoch = 0;
+    const void *spec_ahead_state = nullptr;
     int plan_slot = 0;                             // slot the next trk_run consumes
     bool ahead_valid = false;                      // dplan2[plan_slot] already planned (look-ahead)
     int ahead_nepoch = 0;

@@ -129,7 +129,8 @@ struct GcRound {
 };
 
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
-int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *spec);
+int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims,
+                       int e_off);
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch, int *claims);
 // nco_overflow: device counter of units whose NCO tables did not fit (their outputs are zero)

@@ -58,8 +58,11 @@ namespace {
 // and period.  What is sequential in a batch -- trk_plan2_kernel -- then only evaluates and checks.
 __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
                                                        int *__restrict__ claims_code, int *__restrict__ claims_car,
-                                                       int nch, int nepoch)
+                                                       int nch, int nepoch, int e_off)
 {
+    // e_off: periods between the state handed in and the batch's first period (0: the batch starts at that
+    // state; nepoch: the state is the start of the batch BEFORE this one, whose chain is still running -- the
+    // closed forms reach over it just as well, and the claims are checked either way)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nch * nepoch) return;
     const int ch = i / nepoch, e = i - ch * nepoch;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__
         double remcode, remcarr, dummy;
         int n;
         const double ps = gc_carrier_ps(s.carrfreq, c.ti);
-        gc_spec_start(s.remcode, s.remcarr, ci, spc, ps, dlen, e, &remcode, &remcarr, &n);
+        gc_spec_start(s.remcode, s.remcarr, ci, spc, ps, dlen, e + e_off, &remcode, &remcarr, &n);
         if (n > 0 && n <= (1 << 24)) {
             {
                 GcCodePlan PC;
@@ -122,18 +125,16 @@ __host__ __device__ inline int plan2_class(double ti, double codefreq, int clen,
 // buffer positions), wavefront 1 follows one step behind with the carrier NCO, which needs only the
 // period lengths -- the two chains are independent otherwise and each is latency bound.
 #define GC_PLAN_MAXE 4096          // periods per batch handed from wave to wave through LDS (longer: one wave does both)
-__global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict__ chan,
-                                                       const GcTrkState *__restrict__ state_in,
-                                                       GcTrkState *__restrict__ state_out,
-                                                       GcTrkPlan *__restrict__ plan, int nch, int nepoch, unsigned classmask)
+__device__ __attribute__((noinline)) void trk_plan_body(const GcChan *__restrict__ chan,
+                                                        const GcTrkState *__restrict__ state_in,
+                                                        GcTrkState *__restrict__ state_out,
+                                                        GcTrkPlan *__restrict__ plan, int nch, int nepoch)
 {
     __shared__ int Ks2[2][GC_NB + 2];
     __shared__ int nsh[GC_PLAN_MAXE];
     __shared__ int prog;
     const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (ch >= nch) return;
-    // the channels the batch chain serves (trk_plan2_kernel, launched beside this one)
-    if (classmask && plan2_class(chan[ch].ti, state_in[ch].codefreq, chan[ch].clen, chan[ch].smax) >= 0) return;
     // the chain is latency bound and shares its SIMD with correlator wavefronts of the batch before:
     // let it issue first
     __builtin_amdgcn_s_setprio(3);
@@ -230,6 +231,13 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
         for (int t = 0; t < 6; t++)
             if (tally[t]) atomicAdd(&gc_plan_stats[t], (unsigned long long)tally[t]);
     }
+}
+
+__global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
+                                                       GcTrkState *__restrict__ state_out, GcTrkPlan *__restrict__ plan,
+                                                       int nch, int nepoch)
+{
+    trk_plan_body(chan, state_in, state_out, plan, nch, nepoch);
 }
 
 // ---- the batch planner's chain: evaluate and check (gnsscorr_nco.h: "period steps on claims") ----
@@ -600,7 +608,10 @@ __global__ __launch_bounds__(128) void trk_plan2_kernel(const GcChan *__restrict
     const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (ch >= nch) return;
     const int cls = plan2_class(chan[ch].ti, state_in[ch].codefreq, chan[ch].clen, chan[ch].smax);
-    if (cls < 0) return;            // (trk_plan_kernel serves it)
+    if (cls < 0) {                  // no instance of the batch chain for this channel: the chain that certifies its own crossings
+        trk_plan_body(chan, state_in, state_out, plan, nch, nepoch);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) g_plan2.prog = 0;
     __syncthreads();
@@ -1957,31 +1968,31 @@ static bool trk_nospec()
 }
 
 // claims: 2 * nch * nepoch * GC_CLAIM_ROW ints of scratch (code rows, then carrier rows)
-int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims)
+int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims,
+                       int e_off)
 {
     if (!claims || trk_nospec() || nepoch > GC_PLAN_MAXE) return 0;
     const int total = nch * nepoch;
     hipLaunchKernelGGL(trk_spec_kernel, dim3((total + 63) / 64), dim3(64), 0, st, chan, state_in, claims,
-                       claims + (size_t)nch * nepoch * GC_CLAIM_ROW, nch, nepoch);
+                       claims + (size_t)nch * nepoch * GC_CLAIM_ROW, nch, nepoch, e_off);
     GC_HIP(hipGetLastError());
     return 0;
 }
 
 // claims: filled by gc_launch_trk_spec for the same state and batch -> the batch form of the chain (evaluate and
-// check) for every channel it has an instance for (plan2_class); the chain that certifies its crossings itself,
-// period by period, serves the rest -- and everything when claims is null or the batch is longer than
-// GC_PLAN_MAXE periods.
+// check) for every channel it has an instance for (plan2_class); inside the same launch the chain that certifies
+// its crossings itself, period by period, serves the rest -- and everything when claims is null or the batch is
+// longer than GC_PLAN_MAXE periods.
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,
                        GcTrkPlan *plan, int nch, int nepoch, int *claims)
 {
     static const int dbg = getenv("GNSSCORR_PLAN_DBG") ? atoi(getenv("GNSSCORR_PLAN_DBG")) : 0;
     const bool batch = claims && !trk_nospec() && nepoch <= GC_PLAN_MAXE;
-    if (batch) {
+    if (batch)
         hipLaunchKernelGGL(trk_plan2_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch,
                            claims, claims + (size_t)nch * nepoch * GC_CLAIM_ROW, dbg);
-        GC_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch, batch ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch);
     GC_HIP(hipGetLastError());
     return 0;
 }
