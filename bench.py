@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=1000, help="code periods per channel per launch")
-    ap.add_argument("--inner", type=int, default=8, help="launches per step (so that 20 steps time >= 0.5 s)")
+    ap.add_argument("--inner", type=int, default=32, help="launches per step (so that 20 steps time >= 0.5 s)")
     ap.add_argument("--loop-periods", type=int, default=400, help="periods of the closed-loop legs")
     ap.add_argument("--acq-steps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -329,6 +329,7 @@ def main():
         "kernels_ms_per_launch": {"trk_spec": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_spec")),
                                   "trk_plan": p_ms / max(p_n, 1),
                                   "trk_expand": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_expand")),
+                                  "trk_edges": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_edges")),
                                   "trk_corr": k_ms / max(k_n, 1), "trk_finish": s_ms / max(s_n, 1)},
     }
 

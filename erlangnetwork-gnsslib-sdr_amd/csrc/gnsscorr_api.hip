@@ -91,6 +91,7 @@ static void free_trk_buffers(gnsscorr_ctx *ctx)
 {
     for (int i = 0; i < 2; i++) { hipFree(ctx->dplan2[i]); ctx->dplan2[i] = nullptr; }
     for (int i = 0; i < 2; i++) { hipFree(ctx->dspec2[i]); ctx->dspec2[i] = nullptr; }
+    hipFree(ctx->detab); ctx->detab = nullptr;
     ctx->spec_ahead_valid = false;
     ctx->ahead_valid = false;
     hipFree(ctx->dcorrI); ctx->dcorrI = nullptr;
@@ -595,6 +596,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dspec2[i], sizeof(int) * 2 * units * GC_CLAIM_ROW));
+    GC_HIP(hipMalloc((void **)&ctx->detab, sizeof(unsigned short) * units * GC_EDGTAB));
     ctx->spec_ahead_valid = false;
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
     GC_HIP(hipMalloc((void **)&ctx->dcorrQ, sizeof(double) * units * ctx->ntap));
@@ -716,11 +718,17 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
     if (!ctx->stream2 && ctx->fin_pending[slot]) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[slot], 0));
+    {
+        // start samples of the periods' chip edges, for the correlator's look-up phase
+        GcTimed t(ctx, "trk_edges");
+        rc = gc_launch_trk_edges(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->dsegs2[slot], ctx->detab, ctx->nch, nepoch);
+        if (rc) return rc;
+    }
     for (int dtype = 1; dtype <= 2; dtype++) {
         if (!have[dtype]) continue;
         GcTimed t(ctx, "trk_corr");
         rc = gc_launch_trk_corr(ctx->stream, ctx->dchan, ctx->dunit2[slot], ctx->dsegs2[slot], ctx->drounds2[slot], ctx->dpartial2[slot],
-                                ctx->nch, nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
+                                ctx->nch, nepoch, ctx->nseg, ctx->ntap, dtype, ctx->ntap, ctx->max_n, ctx->smax_max, ctx->detab);
         if (rc) return rc;
     }
     if (ctx->stream2) GC_HIP(hipEventRecord(ctx->ev_corr[slot], ctx->stream));     // slot buffers consumed, partials ready

@@ -101,7 +101,7 @@ static int corr_unit(gnsscorr_ctx *ctx, const int8_t *ring, uint64_t ringlen, in
                               nseg, n, g_once.overflow);
     if (rc) return rc;
     rc = gc_launch_trk_corr(ctx->stream, g_once.chan, g_once.unit, g_once.segs, g_once.rounds, g_once.partial, 1, 1, nseg,
-                            c.ntap, dtype, c.ntap, n, c.smax);
+                            c.ntap, dtype, c.ntap, n, c.smax, nullptr);
     if (rc) return rc;
     rc = gc_launch_trk_finish(ctx->stream, g_once.partial, g_once.out, g_once.out + GNSSCORR_MAXTAPS,
                               g_once.out + 2 * GNSSCORR_MAXTAPS, g_once.out + 3 * GNSSCORR_MAXTAPS, g_once.finish, 1, 1, nseg,
@@ -292,7 +292,7 @@ int cmb_run_group(gnsscorr_ctx *ctx, std::vector<TrkReq *> &grp)
     GC_HIP(hipMemcpyAsync(q.dplan, q.hplan, sizeof(GcTrkPlan) * k, hipMemcpyHostToDevice, st));
     rc = gc_launch_trk_expand(st, q.dchan, q.dplan, q.dunit, q.dsegs, nullptr, k, 1, q.drounds, nseg, max_n, q.doverflow);
     if (rc) return rc;
-    rc = gc_launch_trk_corr(st, q.dchan, q.dunit, q.dsegs, q.drounds, q.dpartial, k, 1, nseg, ntap, dtype, ntap, max_n, smax_max);
+    rc = gc_launch_trk_corr(st, q.dchan, q.dunit, q.dsegs, q.drounds, q.dpartial, k, 1, nseg, ntap, dtype, ntap, max_n, smax_max, nullptr);
     if (rc) return rc;
     double *cI = q.dout, *cQ = q.dout + (size_t)q.cap * ntap, *sI = cQ + (size_t)q.cap * ntap, *sQ = sI + (size_t)q.cap * ntap;
     rc = gc_launch_trk_finish(st, q.dpartial, cI, cQ, sI, sQ, q.dfinish, k, 1, nseg, ntap);

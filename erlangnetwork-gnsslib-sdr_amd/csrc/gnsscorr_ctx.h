@@ -67,6 +67,7 @@ struct gnsscorr_ctx {
     // claims of the batch being planned (discovery pass -> chain), two buffers: while the chain of one batch reads
     // its claims the discovery pass of the NEXT batch fills the other one from the same input state, on its own stream
     int *dspec2[2] = {nullptr, nullptr};
+    unsigned short *detab = nullptr;               // [unit][GC_EDGTAB] start samples of the batch's chip edges (main stream: trk_edges -> trk_corr)
     hipStream_t stream4 = nullptr;                 // discovery-ahead stream
     hipEvent_t ev_spec = nullptr, ev_chain = nullptr;
     bool spec_pending = false;                     // stream4 has work whose end ev_spec marks

@@ -89,7 +89,9 @@ struct GcTrkUnit {
     int      nt;        // replica length n + 2*smax
     int      ncar;      // pieces of the carrier table
     int      ncode;     // pieces of the code table
+    int      eq0, eq1;  // chip edges [eq0, eq1) the period's rounds can touch (their start samples: trk_edges); eq0 < 0: no table
 };
+#define GC_EDGTAB 704   // start samples (uint16) per unit in the edge table: one code period of edges and some
 
 // The unit's two NCOs as piecewise-linear tables (gnsscorr_nco.h): every LUT index and every chip
 // the kernels derive from them equals what the reference's sample-by-sample fp64 sums give.
@@ -136,9 +138,12 @@ int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *sta
 // nco_overflow: device counter of units whose NCO tables did not fit (their outputs are zero)
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit, GcUnitSegs *segs,
                          int *nsamp_out, int nch, int nepoch, GcRound *rounds, int nseg, int max_n, int *nco_overflow);
+int gc_launch_trk_edges(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, unsigned short *etab,
+                        int nch, int nepoch);
 int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs,
                        const GcRound *rounds, int *partial, int nch,
-                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max);
+                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max,
+                       const unsigned short *etab);
 // scratch: GC_FINISH_SCRATCH 64-bit words per channel, zero before the first launch (the kernel leaves them zero)
 #define GC_FINISH_SCRATCH (2 * GNSSCORR_MAXTAPS + 1)
 int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, double *corrQ, double *sumI,

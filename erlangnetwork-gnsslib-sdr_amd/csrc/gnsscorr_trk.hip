@@ -677,6 +677,8 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     u.nt = p.n + 2 * c.smax;
     u.ncar = 0;
     u.ncode = 0;
+    u.eq0 = -1;
+    u.eq1 = -1;
     if (nsamp_out) nsamp_out[i] = p.n;
     const double ci = __dmul_rn(c.ti, p.codefreq);
     // outside the reference's (nsamp+100) scratch (ref src/sdrtrk.c:23), or a chip step for which its
@@ -712,6 +714,7 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
     const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
     const unsigned short *rank = (const unsigned short *)(c.code + 1024);
+    int eq0 = 0x7fffffff, eq1 = -1;
     for (int seg = 0; seg < nseg; seg++) {
         const int g0 = seg * rgrp * rpw;
         if (g0 >= u.G) break;
@@ -730,7 +733,15 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
             ro.w0 = (short)wa;
             ro.hint = hint;
             rounds[((size_t)i * nseg + seg) * GC_MAXR + r] = ro;
+            eq0 = ro.q0 < eq0 ? ro.q0 : eq0;
+            eq1 = ro.q1 > eq1 ? ro.q1 : eq1;
         }
+    }
+    // the edges whose start samples trk_edges tabulates (a period longer than the table, or replica positions
+    // beyond 16 bits: the correlator finds them itself)
+    if (eq1 > eq0 && eq1 - eq0 <= GC_EDGTAB && u.nt < 65535) {
+        unit[i].eq0 = eq0;
+        unit[i].eq1 = eq1;
     }
 }
 
@@ -1098,6 +1109,70 @@ __device__ __forceinline__ int lut_cos(int i)
     return (int)(signed char)((w >> (8 * (i & 3))) & 0xFF);
 }
 
+// start position of the chip an edge-list entry names: B = min{j : T(j) >= m in code period w}, T = the
+// reference's truncated running sum.  The code table holds that sum as pieces y0 + i d: the first piece (from
+// `hint` on) whose last value reaches m holds B, and inside it i = ceil((m - y0)/d), settled by two exact
+// evaluations.  scode: the unit's pieces (LDS).
+__device__ __forceinline__ int gc_edge_start(const GcCodeSeg *scode, int ncode, int ed, int w, int hint)
+{
+    const int m = (int)(short)(ed & 0xFFFF);
+    const double thr = m ? (double)m : -0.5;        // chip 0: any value above -1 truncates to it
+    int sp = hint;
+    bool hit = false;
+    while (true) {
+        const int sw = scode[sp].w;
+        hit = sw > w || (sw == w && scode[sp].ylast >= thr);
+        if (hit || sp + 1 >= ncode) break;
+        sp++;
+    }
+    const int j0 = scode[sp].j0;
+    if (!hit) return j0 + scode[sp].cnt;            // past the replica: clamped away by the look-ups
+    const double d = scode[sp].d, y0 = scode[sp].y0;
+    int i = 0;
+    if (scode[sp].w == w && d != 0.0 && thr > y0) {
+        i = (int)ceil((thr - y0) * scode[sp].inv);
+        if (i < 1) i = 1;
+        if (__fma_rn((double)(i - 1), d, y0) >= thr) i--;
+        else if (__fma_rn((double)i, d, y0) < thr) i++;
+    }
+    return j0 + i;
+}
+
+// Edge table: one workgroup per (channel, period) tabulates the start samples of the chip edges [eq0, eq1) the
+// period's rounds can touch (uint16 each; GC_EDGTAB per unit), so that the correlator's look-up phase reads
+// them instead of searching the code table edge by edge.  Lanes take consecutive edges: neighbours share a piece.
+__global__ __launch_bounds__(256) void trk_edges_kernel(const GcChan *__restrict__ chan, const GcTrkUnit *__restrict__ unit,
+                                                        const GcUnitSegs *__restrict__ segs, unsigned short *__restrict__ etab,
+                                                        int nch, int nepoch)
+{
+    __shared__ __attribute__((aligned(16))) GcCodeSeg scode[GC_NCODE];
+    const int ui = blockIdx.x, tid = threadIdx.x;
+    if (ui >= nch * nepoch) return;
+    const GcTrkUnit u = unit[ui];
+    if (u.n <= 0 || u.eq0 < 0) return;
+    const GcChan &c = chan[ui / nepoch];
+    if (tid < u.ncode) scode[tid] = segs[ui].code[tid];
+    __syncthreads();
+    const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)((gc_gptr_i8)c.code + 3072);
+    const int nedge = c.nedge;
+    unsigned short *out = etab + (size_t)ui * GC_EDGTAB;
+    for (int q = u.eq0 + tid; q < u.eq1; q += 256) {
+        const int w = q / nedge, idx = q - w * nedge;
+        // the piece that holds the edge: pieces are ordered by (code period, value), the test is monotone
+        const int ed = edges[idx];
+        const int m = (int)(short)(ed & 0xFFFF);
+        const double thr = m ? (double)m : -0.5;
+        int lo = 0, hi = u.ncode - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int sw = scode[mid].w;
+            if (sw > w || (sw == w && scode[mid].ylast >= thr)) hi = mid; else lo = mid + 1;
+        }
+        const int js = gc_edge_start(scode, u.ncode, ed, w, lo);
+        out[q - u.eq0] = (unsigned short)(js < 0 ? 0 : (js > 65535 ? 65535 : js));
+    }
+}
+
 template <int DTYPE, int NIT>
 struct PsLayout {
     static constexpr int SPG = 16 / DTYPE;                      // samples per 16-byte group
@@ -1136,7 +1211,8 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 template <int DTYPE, int NTAP, int NIT>
 __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, const GcUnitSegs *__restrict__ gs,
                                         const GcRound *__restrict__ myrounds, int *__restrict__ pout, int ntap_stride,
-                                        int max_n, int rpw, int seg, int ablate, char *smem, int tid)
+                                        int max_n, int rpw, int seg, int ablate, char *smem, int tid,
+                                        const unsigned short *__restrict__ etab_u = nullptr)
 {
     using L = PsLayout<DTYPE, NIT>;
     constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, LPAD = L::LPAD;
@@ -1238,31 +1314,11 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     }
     int wseg = 0;                                       // wave-uniform: carrier piece of the wave's first sample
     bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
-    auto edge_js = [&](int ed, int w, int hint) -> int { // start position of the chip the list entry names
-        // B = min{j : T(j) >= m in code period w}, T = the reference's truncated running sum.  The code
-        // table holds that sum as pieces y0 + i d: the first piece (from the round's first one) whose last
-        // value reaches m holds B, and inside it i = ceil((m - y0)/d), settled by two exact evaluations.
-        const int m = (int)(short)(ed & 0xFFFF);
-        const double thr = m ? (double)m : -0.5;        // chip 0: any value above -1 truncates to it
-        int sp = hint;
-        bool hit = false;
-        while (true) {
-            const int sw = scode[sp].w;
-            hit = sw > w || (sw == w && scode[sp].ylast >= thr);
-            if (hit || sp + 1 >= ncode) break;
-            sp++;
-        }
-        const int j0 = scode[sp].j0;
-        if (!hit) return j0 + scode[sp].cnt;            // past the replica: clamped away by the look-ups
-        const double d = scode[sp].d, y0 = scode[sp].y0;
-        int i = 0;
-        if (scode[sp].w == w && d != 0.0 && thr > y0) {
-            i = (int)ceil((thr - y0) * scode[sp].inv);
-            if (i < 1) i = 1;
-            if (__fma_rn((double)(i - 1), d, y0) >= thr) i--;
-            else if (__fma_rn((double)i, d, y0) < thr) i++;
-        }
-        return j0 + i;
+    // start sample of edge q: from the unit's edge table (trk_edges) when there is one, else searched here
+    const bool have_etab = etab_u != nullptr && u.eq0 >= 0;
+    auto edge_js = [&](int q, int ed, int w, int hint) -> int {
+        if (have_etab) return (int)etab_u[q - u.eq0];
+        return gc_edge_start(scode, ncode, ed, w, hint);
     };
     auto edge_load = [&](int q, int w0, int *w) -> int {  // w0: code periods in front of the round's first edge
         q -= w0 * nedge;
@@ -1366,7 +1422,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         };
         if (!(ablate & 2)) { if (onepiece) run(std::false_type{}); else run(std::true_type{}); }
         // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
-        if (q < q1) js = edge_js(ed, ew, rhint) - roff;
+        if (q < q1) js = edge_js(q, ed, ew, rhint) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
         // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
         // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
@@ -1422,7 +1478,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                     }
                 }
                 q += 256;
-                if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(ed, ew, rhint) - roff; }
+                if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(q, ed, ew, rhint) - roff; }
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
@@ -1465,7 +1521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
                                                           const GcRound *__restrict__ rounds,
                                                           int *__restrict__ partial, int nch, int nepoch, int nseg,
                                                           int ntap_stride, int ntap_lo, int max_n, int rpw,
-                                                          int ablate)
+                                                          int ablate, const unsigned short *__restrict__ etab)
 {
     using L = PsLayout<DTYPE, NIT>;
     // static, so that every LDS address is a compile-time offset
@@ -1485,7 +1541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ?
     const size_t ui = (size_t)ch * nepoch + e;
     const GcTrkUnit u = unit[ui];
     ps_unit<DTYPE, NTAP, NIT>(c, u, segs + ui, rounds + (ui * nseg + seg) * GC_MAXR, partial + (ui * nseg + seg) * 2 * ntap_stride,
-                              ntap_stride, max_n, rpw, seg, ablate, smem, tid);
+                              ntap_stride, max_n, rpw, seg, ablate, smem, tid, etab ? etab + ui * GC_EDGTAB : nullptr);
 }
 
 // Sums the segment partials of every (channel, epoch) into the correlator
@@ -1850,17 +1906,21 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
 int g_trk_nit = 0;      // groups per lane per segment workgroup (1, 2, 4 or 8); 0 = not yet chosen
 int g_trk_algo = 0;     // 1 = prefix-sum form (default), 2 = replica form (GNSSCORR_TRK_ALGO=replica)
 
+// the edge table of the launch being issued (set by gc_launch_trk_corr around the tap-bucket dispatch below)
+static thread_local const unsigned short *t_trk_etab = nullptr;
+
 template <int DTYPE, int NTAP, int NIT>
 int launch_corr_ps(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, const GcRound *rounds, int *partial,
                    int nch, int nepoch, int nseg, int ntap_stride, int ntap_lo, int max_n)
 {
+    const unsigned short *etab = t_trk_etab;
     static_assert(PsLayout<DTYPE, NIT>::bytes(NTAP) <= 64 * 1024, "static LDS image");
     const int rpw = trk_ps_rounds(DTYPE, max_n, NIT);
     static const int ablate = getenv("GNSSCORR_TRK_ABLATE") ? atoi(getenv("GNSSCORR_TRK_ABLATE")) : 0;
     const long long total = 8LL * ((nepoch + 7) / 8) * nch * nseg;
     if (total > 0x7fffffffLL) return gc_fail(GNSSCORR_EINVAL, "trk_corr: batch too large (%lld workgroups)", total);
     hipLaunchKernelGGL((trk_corr_ps_kernel<DTYPE, NTAP, NIT>), dim3((unsigned)total), dim3(256), 0, st, chan, unit,
-                       segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate);
+                       segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap_lo, max_n, rpw, ablate, etab);
     GC_HIP(hipGetLastError());
     return 0;
 }
@@ -2010,17 +2070,34 @@ int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *pl
 
 // One launch serves every channel whose (dtype, tap bucket) matches; callers
 // invoke it once per distinct dtype present in the channel set.
+// etab: the start samples of the periods' chip edges (gc_launch_trk_edges on the same stream before this), or null
 int gc_launch_trk_corr(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs,
                        const GcRound *rounds, int *partial, int nch,
-                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max)
+                       int nepoch, int nseg, int ntap_stride, int dtype, int ntap, int max_n, int smax_max,
+                       const unsigned short *etab)
 {
     trk_pick_nit();
     if (smax_max > 64) return gc_fail(GNSSCORR_EINVAL, "trk_corr: tap offset %d samples (<= 64 supported)", smax_max);
+    static const bool noetab = getenv("GNSSCORR_TRK_NOEDGETAB") != nullptr;
+    t_trk_etab = (g_trk_algo == 1 && !noetab) ? etab : nullptr;
+    int rc = gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
     if (dtype == 2)
-        return launch_corr_taps<2>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
-    if (dtype == 1)
-        return launch_corr_taps<1>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
-    return gc_fail(GNSSCORR_EINVAL, "trk_corr: dtype %d not 1 or 2", dtype);
+        rc = launch_corr_taps<2>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+    else if (dtype == 1)
+        rc = launch_corr_taps<1>(st, chan, unit, segs, rounds, partial, nch, nepoch, nseg, ntap_stride, ntap, max_n, smax_max);
+    t_trk_etab = nullptr;
+    return rc;
+}
+
+int gc_launch_trk_edges(hipStream_t st, const GcChan *chan, const GcTrkUnit *unit, const GcUnitSegs *segs, unsigned short *etab,
+                        int nch, int nepoch)
+{
+    static const bool noetab = getenv("GNSSCORR_TRK_NOEDGETAB") != nullptr;
+    trk_pick_nit();
+    if (!etab || noetab || g_trk_algo != 1) return 0;
+    hipLaunchKernelGGL(trk_edges_kernel, dim3(nch * nepoch), dim3(256), 0, st, chan, unit, segs, etab, nch, nepoch);
+    GC_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int DTYPE>
