@@ -1349,7 +1349,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         int aI = 0, aQ = 0, js = 0;
         const int roff = r * RSAMP;
         // only the first and the last round of a period hold samples outside [0, n)
-        const bool ragged = kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G;
+        const bool ragged = !(ablate & 4) && (kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G);
         // carrier pieces: the wave's 64 * LSP samples start in piece wseg; when no other piece starts
         // inside them (the common case -- a piece is a whole binade of the running phase) every lane
         // steps the same piece, otherwise each lane finds its own and switches where the next one starts
@@ -1358,7 +1358,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         GC_DBG_MARK(7, sk0[wseg + 1]);
         while (sk0[wseg + 1] <= kw) wseg++;
         GC_DBG_MARK(6, 1000 * r + wseg + 500);
-        const bool onepiece = sk0[wseg + 1] >= kw + 64 * LSP;
+        const bool onepiece = (ablate & 8) || sk0[wseg + 1] >= kw + 64 * LSP;
         auto run = [&](auto multi_tag) {
             constexpr bool MULTI = decltype(multi_tag)::value;
             int sp = wseg, knext = 0x7fffffff;

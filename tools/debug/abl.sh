@@ -1,4 +1,4 @@
 for a in 0 1 2 3; do
-  GNSSCORR_TRK_ABLATE=$a timeout -k 10 120 python bench.py --steps 5 --warmup 1 --no-cpu --no-acq --loop-periods 0 2>/dev/null | tail -1 > gpurun_out/abl_$a.json
+  GNSSCORR_TRK_ABLATE=$a timeout -k 10 120 python bench.py --steps 2 --warmup 1 --inner 8 --no-cpu --no-acq --loop-periods 0 2>/dev/null | tail -1 > gpurun_out/abl_$a.json
   python -c "import json; d=json.load(open('gpurun_out/abl_$a.json')); print('ablate', $a, d['kernels_ms_per_launch'])"
 done
