@@ -5,19 +5,9 @@
 #include "gnsscorr_nco.h"
 #include "code_period_prof.h"
 
-struct FillRec {     // GcFillLanes + the crossings kept (one row per period)
-    int lane; int *row;
-    __device__ bool operator()(int *K, const GcCertCtx &c, int i0, int itop, double lim) const {
-        GcFillLanes f{lane};
-        const bool ok = f(K, c, i0, itop, lim);
-        if (lane == 0) { for (int i = 0; i <= GC_NB; i++) row[i] = (ok && i > i0) ? K[i] : 0; row[GC_NB + 1] = ok ? i0 + 1 : 0; }
-        return ok;
-    }
-};
-
 struct Cnt { int n = 0; __host__ __device__ void operator()(int, double, double, int) { n++; } __host__ __device__ void operator()(int, double, double, int, int) { n++; } };
 
-__global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double carrfreq, double codefreq, double *out, long long *clk, int *rows)
+__global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double carrfreq, double codefreq, double *out, long long *clk)
 {
     __shared__ int Ks[GC_NB + 2];
     const int lane = threadIdx.x;
@@ -61,26 +51,6 @@ __global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double ca
         if (mode & 64) { double rp; if (gc_carrier_period(PK, remcarr, n, fill, &rp)) remcarr = rp; else { GcNoEmit ne; c1.n++; remcarr = gc_fast_prem(fprem, gc_fast_carrier_walk(fcar, gc_div_y(remcarr * 32.0, GC_NCO_DPI, ydpi), n, ne)); } }
         if (mode & 128) { double rc; if (gc_code_period(PC, remcode, n + 2 * smax, fill, &rc)) remcode = rc; else { GcNoEmit ne; c2.n++; remcode = gc_fast_code_walk(fcode, gc_code_start_fast(remcode, smaxci, len), len, n + 2 * smax, ne) - smaxci; } }
         if (mode & 256) { double rc; GcNoEmit ne; if (gc_code_period_prof<11>(T, PC, remcode, n + 2 * smax, fill, &rc, ne)) remcode = rc; else c2.n++; }
-        if (mode & 512) {       // record the crossings of both NCOs
-            FillRec fc{lane, rows + (size_t)p * 2 * GC_SPEC_ROW}, fk{lane, rows + (size_t)p * 2 * GC_SPEC_ROW + GC_SPEC_ROW};
-            if (lane == 0) { fc.row[GC_NB + 1] = 0; fk.row[GC_NB + 1] = 0; }
-            double r;
-            if (gc_carrier_period(PK, remcarr, n, fk, &r)) remcarr = r; else c1.n++;
-            if (gc_code_period(PC, remcode, n + 2 * smax, fc, &r)) remcode = r; else c2.n++;
-        }
-        if (mode & (1024 | 2048)) {   // speculated rows, checked
-            GcFillSpec fs;
-            const int4 *rr = reinterpret_cast<const int4 *>(rows) + (size_t)p * 2 * (GC_SPEC_ROW / 4);
-            double r;
-            if (mode & 1024) {
-                for (int q = 0; q < GC_SPEC_ROW / 4; q++) { const int4 v = rr[q]; fs.k[4*q] = v.x; fs.k[4*q+1] = v.y; fs.k[4*q+2] = v.z; fs.k[4*q+3] = v.w; }
-                if (gc_code_period_inl(PC, remcode, n + 2 * smax, fs, &r)) remcode = r; else c2.n++;
-            }
-            if (mode & 2048) {
-                for (int q = 0; q < GC_SPEC_ROW / 4; q++) { const int4 v = rr[GC_SPEC_ROW / 4 + q]; fs.k[4*q] = v.x; fs.k[4*q+1] = v.y; fs.k[4*q+2] = v.z; fs.k[4*q+3] = v.w; }
-                if (gc_carrier_period(PK, remcarr, n, fs, &r)) remcarr = r; else c1.n++;
-            }
-        }
         if (mode & 8) remcode = gc_code_rem(gc_code_walk(gc_code_start(remcode, smax, ci, len), ci, len, n + 2 * smax, c2), smax, ci);
     }
     const long long t1 = wall_clock64();
@@ -90,20 +60,21 @@ __global__ __launch_bounds__(64) void chain_kernel(int mode, int nper, double ca
 
 int main()
 {
-    double *out; long long *clk; int *rows;
+    double *out; long long *clk;
     hipMalloc(&out, 128); hipMalloc(&clk, 8);
     const int nper = 2000;
-    hipMalloc(&rows, sizeof(int) * nper * 2 * GC_SPEC_ROW);
-    for (double cf : {2345.6, -2345.6, 4876.3}) for (int mode : {512, 1024, 2048, 64, 128}) {
+    for (int mode : {128, 256}) for (double cf : {2345.6, -2345.6, 4.0932e6}) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, mode, 10, cf, 1.023e6 + 1.3, out, clk);
         hipEventRecord(a);
-        hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, mode, nper, cf, 1.023e6 + 1.3, out, clk, rows);
+        hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, mode, nper, cf, 1.023e6 + 1.3, out, clk);
         hipEventRecord(b);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, a, b);
         double h[10]; long long c; hipMemcpy(h, out, 80, hipMemcpyDeviceToHost); hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-        printf("mode %4d carr %.1f: %.3f us/period, misses car %.0f code %.0f, rem %.9g %.9g\n", mode, cf,
-               (double)c / 100.0 / nper, h[2], h[3], h[0], h[1]);
+        if (mode & 256) printf("  shader clocks/period: head %.0f literal %.0f fill %.0f chain %.0f tail %.0f\n", h[4], h[5], h[6], h[7], h[8]);
+        printf("mode %d carr %.1f: %.3f us/period (%.0f wall-clock ticks/period), pieces/period car %.1f code %.1f, rem %.6g %.6g\n", mode, cf,
+               ms * 1e3 / nper, (double)c / nper, h[2] / nper, h[3] / nper, h[0], h[1]);
     }
     return 0;
 }
