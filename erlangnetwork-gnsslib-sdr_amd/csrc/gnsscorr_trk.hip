@@ -1348,12 +1348,13 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
         int aI = 0, aQ = 0, js = 0;
         const int roff = r * RSAMP;
-        // only the first and the last round of a period hold samples outside [0, n)
-        const bool ragged = !(ablate & 4) && (kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G);
+        const int kw = kl + wv * 64 * LSP;
+        // only the wavefronts that hold the period's first or last sample see samples outside [0, n) (one in
+        // the first round, one or two in the last): the others skip the blanking test altogether
+        const bool ragged = !(ablate & 4) && (kw < 0 || kw + 64 * LSP > n || g0 + r * RGRP + (wv + 1) * 64 * NIT > G);
         // carrier pieces: the wave's 64 * LSP samples start in piece wseg; when no other piece starts
         // inside them (the common case -- a piece is a whole binade of the running phase) every lane
         // steps the same piece, otherwise each lane finds its own and switches where the next one starts
-        const int kw = kl + wv * 64 * LSP;
         GC_DBG_MARK(6, 1000 * r + wseg);
         GC_DBG_MARK(7, sk0[wseg + 1]);
         while (sk0[wseg + 1] <= kw) wseg++;
