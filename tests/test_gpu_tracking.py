@@ -248,12 +248,16 @@ eng.trk_run(5)
 II, QQ, ns = eng.trk_fetch()
 print(json.dumps(dict(II=II.tolist(), QQ=QQ.tolist(), ns=ns.tolist())))
 """)
-    env = dict(os.environ, GNSSCORR_TRK_ALGO="replica")
-    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert np.array_equal(np.array(r["ns"]), ns)
-    assert np.array_equal(np.array(r["II"]), II) and np.array_equal(np.array(r["QQ"]), QQ)
+    # ... and so must the default form without its per-period edge table (the correlator then finds the
+    # start sample of every chip edge itself, as the closed-loop kernel does) and with the older planner
+    # chain (every period certifying its own binade crossings instead of checking discovered ones)
+    for env_add in (dict(GNSSCORR_TRK_ALGO="replica"), dict(GNSSCORR_TRK_NOEDGETAB="1"), dict(GNSSCORR_TRK_NOSPEC="1")):
+        env = dict(os.environ, **env_add)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert np.array_equal(np.array(r["ns"]), ns), env_add
+        assert np.array_equal(np.array(r["II"]), II) and np.array_equal(np.array(r["QQ"]), QQ), env_add
 
 
 def test_planner_chain_long_batch(gc, orc, engine):
