@@ -251,7 +251,7 @@ struct Plan2Shared {
     int nsh[GC_PLAN_MAXE];
     int prog;
     int pad[3];
-    int rows[2][2][GC_PLAN_BLK * GC_CLAIM_ROW];
+    int rows[2][2][(GC_PLAN_BLK + 1) * GC_CLAIM_ROW];     // (+1 row: the row after a block's last is read, never used)
 };
 
 #ifdef GC_PLAN_PROF
@@ -382,7 +382,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
     gc_code_stepc_init(SC, PC);
     const double yspc = __ddiv_rn(1.0, spc);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
-    int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[0];
+    int (*rows)[(GC_PLAN_BLK + 1) * GC_CLAIM_ROW] = g_plan2.rows[0];
     constexpr int RQ = GC_CLAIM_ROW / 4;
     // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
     // until they are used, so the next period's row really is in flight during this period's step)
@@ -430,7 +430,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
         for (int e = e0; e < e1; e++) {
             GC_PP(0);
             GcCodeClaims cl = nx;
-            if (e + 1 < e1) {                       // the next period's claims, in flight during this one
+            {                                       // the next period's claims, in flight during this one
                 const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
 #pragma unroll
@@ -509,7 +509,7 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
     gc_car_plan_init(PK, ps, false, false);
     GcCarStepC CK;
     gc_car_stepc_init(CK, PK, c.nsamp + 16);
-    int (*rows)[GC_PLAN_BLK * GC_CLAIM_ROW] = g_plan2.rows[1];
+    int (*rows)[(GC_PLAN_BLK + 1) * GC_CLAIM_ROW] = g_plan2.rows[1];
     constexpr int RQ = GC_CLAIM_ROW / 4;
     // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
     // until they are used, so the next period's row really is in flight during this period's step)
@@ -561,13 +561,13 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
             GC_PP(5);
             GcCarClaims cl = nx;
             const int n = nn;
-            if (e + 1 < e1) {
+            {
                 const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
 #pragma unroll
                 for (int q = 0; q < RQ; q++) v[q] = r[q];
                 nx = plan2_car_row(v);
-                nn = g_plan2.nsh[e + 1];
+                nn = g_plan2.nsh[e + 1 < GC_PLAN_MAXE ? e + 1 : e];
             }
             const bool mine = lane == e - e0;
             k_phi = mine ? s.remcarr : k_phi;
