@@ -1323,12 +1323,12 @@ template <int N>
 GC_HD double gc_pick(const double (&a)[N], int idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef double gc_vec16 __attribute__((ext_vector_type(16)));
+    typedef double gc_vecn __attribute__((ext_vector_type(N)));
     static_assert(N <= 16, "gc_pick: at most 16 values");
-    gc_vec16 v;
+    gc_vecn v;
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = a[i < N ? i : N - 1];
-    return v[idx & 15];
+    for (int i = 0; i < N; i++) v[i] = a[i];
+    return v[idx < N ? idx : N - 1];
 #else
     return a[idx];
 #endif

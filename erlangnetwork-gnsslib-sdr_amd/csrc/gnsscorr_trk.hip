@@ -310,6 +310,15 @@ __device__ __forceinline__ GcCarClaims plan2_car_row(const int4 (&v)[GC_CLAIM_RO
     c.dm[11] = v[4].x; c.dm[12] = v[4].y; c.pad[0] = 0; c.pad[1] = 0;
     return c;
 }
+// "these claims are here": the LDS reads that brought them were issued a period ago.  Said before the next
+// period's reads are issued, it keeps the compiler from waiting for THOSE at the first use of these.
+template <class T>
+__device__ __forceinline__ void plan2_touch(T &c)
+{
+    int *p = reinterpret_cast<int *>(&c);
+#pragma unroll
+    for (int i = 0; i < GC_CLAIM_ROW; i++) asm volatile("" : "+v"(p[i]));
+}
 static_assert(sizeof(GcCodeClaims) == GC_CLAIM_ROW * 4 && sizeof(GcCarClaims) == GC_CLAIM_ROW * 4, "claims rows are GC_CLAIM_ROW ints");
 static_assert(offsetof(GcCodeClaims, dm) == 20 && offsetof(GcCarClaims, dm) == 20, "claims layout");
 
@@ -430,6 +439,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
         for (int e = e0; e < e1; e++) {
             GC_PP(0);
             GcCodeClaims cl = nx;
+            plan2_touch(cl);
             {                                       // the next period's claims, in flight during this one
                 const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
@@ -440,7 +450,7 @@ __device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTr
             const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
             double qn = gc_div_y(num, spc, yspc);
             if (__builtin_expect(!fastdiv, 0)) qn = __ddiv_rn(num, spc);
-            const int n = (qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0;
+            const int n = plan2_uni((qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0);     // (the same in every lane)
             const bool mine = lane == e - e0;
             k_buff = mine ? s.buffloc : k_buff;
             k_coff = mine ? s.remcode : k_coff;
@@ -560,7 +570,8 @@ __device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrk
         for (int e = e0; e < e1; e++) {
             GC_PP(5);
             GcCarClaims cl = nx;
-            const int n = nn;
+            plan2_touch(cl);
+            const int n = plan2_uni(nn);
             {
                 const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
                 int4 v[RQ];
