@@ -1280,7 +1280,8 @@ GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc
 // step holds.
 #define GC_CLAIM_ROW   20           // ints per (channel, period) row of either NCO
 #define GC_CLAIM_LIT   5            // code: literal additions after the first wrap, at most (as gc_code_period_body)
-#define GC_CLAIM_TAIL  15           // code: literal additions after the second wrap, at most
+#define GC_CLAIM_TAIL  15           // code: literal additions after the second wrap, at most (tap offsets up to 7 samples: 8 positions)
+#define GC_CLAIM_TAIL2 32           // ... for correlator spacings up to 30 samples (the shipped CORRN=6, CORRD=3: 18)
 #define GC_CLAIM_CLIT  8            // carrier: literal additions next to zero, at most (as gc_carrier_period)
 #define GC_CLAIM_CSEG  13           // carrier: binade segments, at most
 #define GC_CLAIM_PREM  12           // carrier: subtractions of DPI in the remainder loop, at most (12: up to ~11 kHz at 1 ms)
@@ -1323,12 +1324,28 @@ template <int N>
 GC_HD double gc_pick(const double (&a)[N], int idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef double gc_vecn __attribute__((ext_vector_type(N)));
-    static_assert(N <= 16, "gc_pick: at most 16 values");
-    gc_vecn v;
+    static_assert(N <= 48, "gc_pick: at most 48 values");
+    if constexpr (N <= 16) {
+        typedef double gc_vecn __attribute__((ext_vector_type(N)));
+        gc_vecn v;
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] = a[i];
-    return v[idx < N ? idx : N - 1];
+        for (int i = 0; i < N; i++) v[i] = a[i];
+        return v[idx < N ? idx : N - 1];
+    } else {
+        // sixteen at a time, then the chunk (the index is the same in every lane: scalar selects)
+        typedef double gc_vec16 __attribute__((ext_vector_type(16)));
+        constexpr int NC = (N + 15) / 16;
+        double r = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            gc_vec16 v;
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = a[c * 16 + i < N ? c * 16 + i : N - 1];
+            const double rc = v[idx & 15];
+            r = (idx >> 4) == c ? rc : r;
+        }
+        return r;
+    }
 #else
     return a[idx];
 #endif
@@ -1483,7 +1500,7 @@ GC_HD bool gc_code_claims_itop(const GcCodePlan &P, double remcode, int nt, GcCo
 {
     GcCodeStepC<ITOP> C;
     gc_code_stepc_init(C, P);
-    return gc_code_claims_step<ITOP, GC_CLAIM_TAIL, DISCOVER>(P, C, remcode, nt, cl, remcode_out);
+    return gc_code_claims_step<ITOP, GC_CLAIM_TAIL2, DISCOVER>(P, C, remcode, nt, cl, remcode_out);     // (the widest tail: claims carry counts, not the instance)
 }
 
 template <bool DISCOVER>

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__
 __device__ unsigned long long gc_plan_stats[8];
 
 // Which instance of the batch chain serves a channel: the table binade that holds the code length (the shape
-// of the code step: 2..64 samples per chip give 7..12) and whether the tail fits 8 positions.  -1: none
+// of the code step: 2..64 samples per chip give 7..12) and whether the tail fits 8, 15 or 32 positions.  -1: none
 // (the chain below serves it).  Host and device use the same function.
 __host__ __device__ inline int plan2_class(double ti, double codefreq, int clen, int smax)
 {
@@ -118,7 +118,8 @@ __host__ __device__ inline int plan2_class(double ti, double codefreq, int clen,
     if (!(ci > 0.0) || es <= 60 || es >= 0x7FF - GC_NB - 4) return -1;
     const int itop = gc_expo(gc_u2d(gc_d2u((double)clen) - 1)) - (es + 2);
     if (itop < 7 || itop > 12) return -1;
-    return (itop - 7) * 2 + (smax + 1 > 8 ? 1 : 0);
+    if (smax + 1 > GC_CLAIM_TAIL2) return -1;      // (tail longer than the widest instance: the certifying chain)
+    return (itop - 7) * 3 + (smax + 1 > 8 ? (smax + 1 > GC_CLAIM_TAIL ? 2 : 1) : 0);
 }
 
 // Two wavefronts per channel: wavefront 0 chains the code NCO (and with it the samples per period and the
@@ -638,16 +639,22 @@ __global__ __launch_bounds__(128) void trk_plan2_kernel(const GcChan *__restrict
     switch (cls) {
     case 0:  plan2_code_wave<7, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     case 1:  plan2_code_wave<7, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 2:  plan2_code_wave<8, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 3:  plan2_code_wave<8, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 4:  plan2_code_wave<9, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 5:  plan2_code_wave<9, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 6:  plan2_code_wave<10, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 7:  plan2_code_wave<10, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 8:  plan2_code_wave<11, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 9:  plan2_code_wave<11, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 10: plan2_code_wave<12, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    default: plan2_code_wave<12, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 2:  plan2_code_wave<7, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 3:  plan2_code_wave<8, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 4:  plan2_code_wave<8, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 5:  plan2_code_wave<8, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 6:  plan2_code_wave<9, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 7:  plan2_code_wave<9, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 8:  plan2_code_wave<9, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 9:  plan2_code_wave<10, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 10: plan2_code_wave<10, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 11: plan2_code_wave<10, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 12: plan2_code_wave<11, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 13: plan2_code_wave<11, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 14: plan2_code_wave<11, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 15: plan2_code_wave<12, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    case 16: plan2_code_wave<12, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    default: plan2_code_wave<12, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
     }
 }
 

@@ -291,6 +291,29 @@ def test_planner_chain_long_batch(gc, orc, engine):
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
 
 
+def test_planner_chain_wide_correlator_spacing(gc, orc, engine):
+    """The shipped front-end files' correlator set (CORRN=6, CORRD=3, CORRP=6: 13 taps, outermost 18 samples,
+    ref frontend/iffile.ini) on int8 IQ: the replica starts 18 samples before the period and ends 18 after it,
+    which the batch planner's widest tail instance covers -- 120 periods chained, bit for bit, and served by
+    the batch form."""
+    nepoch = 120
+    nsamples = 16368 * (nepoch + 12)
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 6, 3, 6, prns=[4, 17, 25, 32], nsamples=nsamples,
+                                       seed=1213, buffloc0=40)
+    stats = np.zeros(8, dtype=np.uint64)
+    gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
+    engine.trk_run(nepoch)
+    II, QQ, ns = engine.trk_fetch()
+    fin = engine.trk_get_state()
+    gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
+    assert stats[0] >= 0.9 * stats[:3].sum() and stats[:3].sum() >= len(chans) * nepoch, stats
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, nepoch)
+    assert np.array_equal(ns, ons)
+    for a, b in zip(fin, ofin):
+        assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
+    assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+
+
 def test_trk_20msps_period(gc, orc, engine):
     """A 20 Msps front end (ref frontend/stereo_L1G1.ini): 20000 samples per code period, five rounds of the
     correlator per period."""
