@@ -130,7 +130,7 @@ struct GcRound {
     int hint;           // code piece that holds the round's first replica position
 };
 
-// kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_acq.hip)
+// kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_plan.hip / gnsscorr_acq.hip)
 int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims,
                        int e_off);
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,

@@ -154,7 +154,7 @@ int nco_period_tables(double ti, double freq, double remcarr, double codefreq, i
     return r;
 }
 
-// The batch planner's steps on claims (trk_spec_kernel discovers, trk_plan2_kernel evaluates): state after every
+// The batch planner's steps on claims (gnsscorr_plan.hip: trk_spec_kernel discovers, trk_plan2_kernel evaluates): state after every
 // period; hits[0]/[1]: periods the code / carrier evaluation served, the rest go to the certified steps
 // ([2]/[3]) and the walkers ([4]/[5]).  shift_*: added to the discovering run's start values.
 void nco_claims_chain(double ti, double f_sf, double freq, double codefreq, int len, int smax, double remcode0, double remcarr0,
