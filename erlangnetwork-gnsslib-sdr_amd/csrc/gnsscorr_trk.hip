@@ -6,9 +6,9 @@
 // src/sdrtrk.c:31-43), for every (channel, code period) of a batch in one
 // launch.
 //
-//   trk_plan : one lane per channel walks the batch's code periods and emits
-//              (buffloc, currnsamp, code phase, carrier phase) per period --
-//              the closed-form NCO chain of sdrtracking()/mixcarr()/rescode().
+//   (the planner -- the exact NCO chain from period to period -- is gnsscorr_plan.hip)
+//   trk_expand / trk_edges : per (channel, period) the NCO piece tables, ring offsets, chip-edge ranges and
+//              the start samples of the chip edges.
 //   trk_corr : one 256-thread workgroup per (channel, period).  The period's
 //              resampled +-1 replica is built once in LDS, the int8 IF window
 //              is streamed from the HBM ring with 16-byte coalesced loads
