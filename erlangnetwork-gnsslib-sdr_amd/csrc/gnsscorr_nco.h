@@ -1102,8 +1102,13 @@ GC_HD bool gc_code_period_body(const GcCodePlan &P, double remcode, int nt, Fill
 
 // (out of line: inlined six times into the closed-loop kernel the step made that kernel hang -- a
 // compiler-sensitive failure)
+#ifdef GC_CODE_PERIOD_INLINE        // (tools/debug: the r2 build in which the closed-loop kernel stalled)
+#define GC_PERIOD_ATTR GC_HD
+#else
+#define GC_PERIOD_ATTR GC_HD_NOINLINE
+#endif
 template <int ITOP, class Fill, class Emit>
-GC_HD_NOINLINE bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
+GC_PERIOD_ATTR bool gc_code_period_t(const GcCodePlan &P, double remcode, int nt, Fill &fill, double *remcode_out, Emit &emit)
 {
     return gc_code_period_body<ITOP>(P, remcode, nt, fill, remcode_out, emit);
 }

@@ -103,7 +103,16 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     }
     u.ncar = ct.n;
     u.ncode = dt.n;
-    if (ct.overflow || dt.overflow) {
+    // what the correlator's scans rely on: carrier pieces start at sample 0 and at increasing samples, code pieces
+    // are non-empty, contiguous and cover the nt replica positions (anything else is reported, never correlated)
+    bool bad = ct.overflow || dt.overflow || ct.n < 1 || dt.n < 1;
+    if (!bad) {
+        bad = sg->carK0[0] != 0;
+        for (int q = 0; q + 1 < ct.n; q++) bad = bad || !(sg->carK0[q] < sg->carK0[q + 1]);
+        for (int q = 0; q < dt.n; q++)
+            bad = bad || sg->code[q].cnt <= 0 || sg->code[q].j0 + sg->code[q].cnt != (q + 1 < dt.n ? sg->code[q + 1].j0 : u.nt);
+    }
+    if (bad) {
         if (nco_overflow) atomicAdd(nco_overflow, 1);
         u.n = 0;
         unit[i] = u;
@@ -759,18 +768,25 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // carrier pieces: the wave's 64 * LSP samples start in piece wseg; when no other piece starts
         // inside them (the common case -- a piece is a whole binade of the running phase) every lane
         // steps the same piece, otherwise each lane finds its own and switches where the next one starts
-        GC_DBG_MARK(6, 1000 * r + wseg);
-        GC_DBG_MARK(7, sk0[wseg + 1]);
+        // (every scan over the piece starts is bounded by the piece count: it never depends on the closing
+        // sentinel alone -- an LDS read past the table returns 0 and would keep an unbounded scan going for ever)
+#ifdef GC_UNBOUNDED_SCANS       // (tools/debug: the round-2 form, kept to reproduce its stall)
         while (sk0[wseg + 1] <= kw) wseg++;
-        GC_DBG_MARK(6, 1000 * r + wseg + 500);
-        const bool onepiece = (ablate & 8) || sk0[wseg + 1] >= kw + 64 * LSP;
+#else
+        while (wseg + 1 < ncar && sk0[wseg + 1] <= kw) wseg++;
+#endif
+        const bool onepiece = (ablate & 8) || wseg + 1 >= ncar || sk0[wseg + 1] >= kw + 64 * LSP;
         auto run = [&](auto multi_tag) {
             constexpr bool MULTI = decltype(multi_tag)::value;
             int sp = wseg, knext = 0x7fffffff;
             const int kb0 = kl + tl * LSP;
             if (MULTI) {
+#ifdef GC_UNBOUNDED_SCANS
                 while (sk0[sp + 1] <= kb0) sp++;
-                knext = sk0[sp + 1];
+#else
+                while (sp + 1 < ncar && sk0[sp + 1] <= kb0) sp++;
+#endif
+                knext = sp + 1 < ncar ? sk0[sp + 1] : 0x7fffffff;
             }
             unsigned long long dfx = scar[sp].dfx;
             unsigned long long phi = scar[sp].fx + (unsigned long long)(long long)(kb0 - sk0[sp]) * dfx;
@@ -804,11 +820,11 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
 #pragma unroll
                 for (int i = 0; i < SPG; i++) {
                     if (MULTI) {
-                        if (kb + i == knext) {          // the next piece starts at this sample
+                        if (kb + i == knext) {          // the next piece starts at this sample (sp + 1 < ncar: knext is its start)
                             sp++;
                             phi = scar[sp].fx;
                             dfx = scar[sp].dfx;
-                            knext = sk0[sp + 1];
+                            knext = sp + 1 < ncar ? sk0[sp + 1] : 0x7fffffff;
                         }
                     }
                     const int pos = DTYPE == 2 ? (i & 1) : (i & 3);
@@ -1035,10 +1051,23 @@ __device__ __forceinline__ void loop_dll(gnsscorr_loop_t *L, GcTrkState &st, int
     L->codeErr = codeErr;
 }
 
-// emitters that fill the correlator's LDS tables in place (lane-uniform calls from the planning wavefront)
+// emitters that fill the correlator's LDS tables in place (lane-uniform calls from the planning wavefront).
+// The table pointers are LDS-typed (address space 3), so every access is a DS instruction: DS instructions of one
+// wavefront execute in order.  Through generic pointers the stores become FLAT instructions, which reach the LDS by
+// way of the texture path and may be overtaken by a DS read issued after them (CDNA ISA: FLAT completes out of
+// order with DS) -- the reader (same wavefront: the rounds of the period; gc_code_chip_at) then sees the previous
+// period's pieces.  DESIGN.md section 6.
+#ifdef GC_LOOP_FLAT_TABLES          // (tools/debug: the round-2 form, generic pointers)
+#define GC_LDS
+#else
+#define GC_LDS __attribute__((address_space(3)))
+#endif
+typedef GC_LDS int *gc_lds_int;
+typedef GC_LDS GcCarSeg *gc_lds_car;
+typedef GC_LDS GcCodeSeg *gc_lds_code;
 struct LdsCarTable {
-    int *k0;
-    GcCarSeg *seg;
+    gc_lds_int k0;
+    gc_lds_car seg;
     int n, overflow;
     __device__ void operator()(int k, double x, double d, int)
     {
@@ -1046,7 +1075,35 @@ struct LdsCarTable {
         if (n > 0 && s.fx == 0 && s.dfx == 0 && seg[n - 1].fx == 0 && seg[n - 1].dfx == 0) return;
         if (n >= GC_NCAR) { overflow = 1; return; }
         k0[n] = k;
-        seg[n] = s;
+        seg[n].fx = s.fx;
+        seg[n].dfx = s.dfx;
+        n++;
+    }
+};
+// GcCodeTable (gnsscorr_nco.h) on an LDS-typed table
+struct LdsCodeTable {
+    gc_lds_code seg;
+    int cap, n, overflow;
+    __device__ void operator()(int j, double y, double d, int count, int w)
+    {
+        GC_FP_STRICT
+        const double yl = fma((double)(count - 1), d, y);
+        if (n > 0 && seg[n - 1].w == w && seg[n - 1].y0 > -1.0 && seg[n - 1].ylast < 1.0 && y > -1.0 && yl < 1.0) {
+            seg[n - 1].cnt += count;
+            seg[n - 1].ylast = yl;
+            seg[n - 1].d = 0.0;
+            seg[n - 1].inv = 0.0;
+            return;
+        }
+        if (n >= cap) { overflow = 1; return; }
+        seg[n].y0 = y;
+        seg[n].d = count > 1 ? d : 0.0;
+        seg[n].inv = (count > 1 && d != 0.0) ? 1.0 / d : 0.0;
+        seg[n].ylast = yl;
+        seg[n].j0 = j;
+        seg[n].cnt = count;
+        seg[n].w = w;
+        seg[n].pad = 0;
         n++;
     }
 };
@@ -1092,10 +1149,15 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
     // wavefront 0 keeps the chained state in registers; the step tables of the two NCOs live in LDS (in
     // registers they would push the correlator's accumulators out)
     GcTrkState st = state[ch];
+#ifdef GC_LOOP_PLAN_IN_REGS         // (tools/debug: the round-2 form that stalled)
+    GcCodePlan PC;
+    GcCarPlan PK;
+#else
     __shared__ GcCodePlan sPC;
     __shared__ GcCarPlan sPK;
     GcCodePlan &PC = sPC;
     GcCarPlan &PK = sPK;
+#endif
     GcFillLanes fill{lane};
     double lastcarr = 0.0, lastcode = 0.0;
     bool have_plan = false;
@@ -1131,8 +1193,8 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                 const bool valid = n > 0 && n <= max_n && ci > 0.0 && ci < dlen;
                 GC_DBG_MARK(0, 100 * p + 1);
                 if (valid) {
-                    LdsCarTable ct{sk0, scar, 0, 0};
-                    GcCodeTable dt{scode, GC_NCODE, 0, 0};
+                    LdsCarTable ct{(gc_lds_int)sk0, (gc_lds_car)scar, 0, 0};
+                    LdsCodeTable dt{(gc_lds_code)scode, GC_NCODE, 0, 0};
                     double r;
                     if (gc_carrier_period(PK, st.remcarr, n, fill, &r, ct)) {
                         remcarr = r;
@@ -1158,7 +1220,18 @@ __global__ __launch_bounds__(256) void trk_loop_kernel(const GcChan *__restrict_
                     GC_DBG_MARK(0, 100 * p + 5);
                     u.ncar = ct.n;
                     u.ncode = dt.n;
-                    if (ct.overflow || dt.overflow) {
+                    // what the correlator's scans rely on: carrier pieces start at sample 0 and at increasing samples,
+                    // code pieces are non-empty, contiguous and cover the nt replica positions
+                    bool bad = ct.n < 1 || dt.n < 1 || ct.overflow || dt.overflow;
+                    if (!bad) {
+                        if (lane == 0) bad = sk0[0] != 0;
+                        if (lane + 1 < ct.n) bad = bad || !(sk0[lane] < sk0[lane + 1]);
+                        if (lane < dt.n) {
+                            const int je = scode[lane].j0 + scode[lane].cnt;
+                            bad = bad || scode[lane].cnt <= 0 || je != (lane + 1 < dt.n ? scode[lane + 1].j0 : nt);
+                        }
+                    }
+                    if (__any(bad)) {
                         if (lane == 0) atomicAdd(nco_overflow, 1);
                         u.n = 0;
                     }

@@ -3,10 +3,12 @@ branch (ref src/sdrmain.c:264-312: sdrtracking, cumsumcorr, pll, dll, clearcumsu
 flagsync / swloop cadence of src/sdrnav.c:241-262).
 
 Bar: correlator sums, samples per period, the filter-update flags and the NCO remainders bit for bit over
-hundreds of periods; filter states and frequencies to 1e-12 relative (atan2/atan of the device maths
-library may differ from the host's in the last bit) -- and since every period's NCO tables are built
-from those frequencies, identical sums over hundreds of periods also say the frequencies stayed
-within a few ulps."""
+hundreds of periods.  The loop filters call atan2 / atan (ref src/sdrtrk.c:106-113), whose last bit belongs to
+the maths library: the device's and glibc's differ in about one call in three, and a frequency that differs by
+one ulp can change a binade's rounded NCO step, i.e. the remainders after thousands of samples (measured: 1.4e-11
+rad after 208 periods, tools/debug/loop_drift.py).  So every period's filter outputs are compared with the
+oracle's from IDENTICAL inputs (1e-14: a few ulps) and then handed to the oracle (`_adopt`): what is held bit
+for bit is everything the library's rounding does not touch -- which is everything else."""
 import ctypes as C
 
 import numpy as np
@@ -24,8 +26,19 @@ def _signal(gc, synth, prns, dop, cph, nper, dtype=2, f_if=0.0, cn0=47.0, seed=4
     return synth.make_if(codes, 16368 * nper, f_sf=F_SF, f_if=f_if, dtype=dtype, sats=sats, seed=seed)
 
 
-def _close(a, b, tol=1e-12):
+def _close(a, b, tol=1e-14):
     return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+
+
+FILTER_FIELDS = ("carrfreq", "codefreq", "carrNco", "codeNco", "carrErr", "codeErr", "freqErr")
+
+
+def _adopt(o, r, where):
+    """This period's filter outputs: equal to the oracle's to a few ulps (same inputs), then the oracle continues
+    from the device's values, so that the next period starts from identical frequencies on both sides."""
+    for f in FILTER_FIELDS:
+        assert _close(float(r[f]), getattr(o, f)), (where, f, float(r[f]), getattr(o, f))
+        setattr(o, f, float(r[f]))
 
 
 def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, flagsync, chunks):
@@ -72,9 +85,7 @@ def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, fl
                 r = log[i, e]
                 assert r["flagloopfilter"] == o.flagloopfilter, where
                 assert r["remcode"] == o.remcode and r["remcarr"] == o.remcarr, where
-                assert _close(r["carrfreq"], o.carrfreq) and _close(r["codefreq"], o.codefreq), where
-                assert _close(r["carrNco"], o.carrNco) and _close(r["codeNco"], o.codeNco), where
-                assert _close(r["carrErr"], o.carrErr) and _close(r["codeErr"], o.codeErr) and _close(r["freqErr"], o.freqErr), where
+                _adopt(o, r, where)
         done += nrun
     fin = engine.trk_get_state()
     lst = engine.loop_get()
@@ -131,3 +142,83 @@ def test_closed_loop_stops_where_data_ends(gc, orc, synth, engine):
     engine.trk_run_loop(10)
     _, ndone2 = engine.trk_fetch_log()
     assert np.all(ndone2 == 10)
+
+
+def _check_against_oracle(orc, engine, ochs, ring, bufflocs, nrun, ntap, done=0):
+    """One trk_run_loop(nrun) against nrun oracle steps per channel: sums, samples, flags and remainders bit for
+    bit, filter states to 1e-12."""
+    L = orc.lib()
+    engine.trk_run_loop(nrun)
+    II, QQ, ns = engine.trk_fetch()
+    log, ndone = engine.trk_fetch_log()
+    assert np.all(ndone == nrun), ndone
+    for i, o in enumerate(ochs):
+        for e in range(nrun):
+            assert L.orc_sdrthread_step(C.byref(o), C.byref(ring), C.byref(bufflocs[i])) == 1
+            where = (i, done + e)
+            assert ns[i, e] == o.currnsamp, where
+            assert np.array_equal(II[i, e], np.ctypeslib.as_array(o.II)[:ntap]), where
+            assert np.array_equal(QQ[i, e], np.ctypeslib.as_array(o.QQ)[:ntap]), where
+            r = log[i, e]
+            assert r["flagloopfilter"] == o.flagloopfilter, where
+            assert r["remcode"] == o.remcode and r["remcarr"] == o.remcarr, where
+            _adopt(o, r, where)
+
+
+def test_closed_loop_bench_configuration_32_channels(gc, orc, synth, engine):
+    """The closed-loop leg of bench.py as a parity case: the 32 channels of BASELINE configs[2] from the bench's
+    own start states (seed 20240601: frequencies anywhere in +-5 kHz, most channels on no satellite, so the loops
+    wander), filter update every period (flagsync = 0), 320 periods in one launch and 30 more in a second.  (A
+    round-2 build of the closed-loop kernel stalled on the device in this configuration after 257 periods: the
+    scans over the period's carrier pieces relied on a closing sentinel alone)"""
+    NSAMP, seed, nper = 16368, 20240601, 350
+    prns = list(range(1, 33))
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in prns}
+    sats = synth.default_sats(prns, seed=seed)
+    data = synth.make_if(codes, (nper + 4) * NSAMP, f_sf=F_SF, f_if=0.0, dtype=2, sats=sats, seed=seed)
+    nsamples = data.shape[0]
+    engine.ring_create(1, 2, nsamples)
+    engine.ring_push_raw(1, data, nsamples)
+    chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in prns]
+    engine.set_channels(chans)
+    rng = np.random.default_rng(seed)
+    states0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)),
+                    remcode=float(rng.uniform(0.01, 0.99)), remcarr=float(rng.uniform(0, 6.2)),
+                    buffloc=int(rng.integers(0, NSAMP))) for c in chans]
+    engine.trk_set_state(states0)
+    ring = orc.make_ring(data, nsamples, nsamples)
+    ochs, bufflocs, loops = [], [], []
+    for i, (c, st) in enumerate(zip(chans, states0)):
+        acqfreq = 200.0 * round(st["carrfreq"] / 200.0)
+        o = orc.make_chan(c.prn, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+        o.acq.acqfreq = acqfreq
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
+        o.flagsync, o.synci, o.cnt = 0, (7 * i) % 20, 2001
+        ochs.append(o)
+        bufflocs.append(C.c_uint64(st["buffloc"]))
+        loops.append(engine.loop_state(i, acqfreq, flagsync=0, synci=o.synci, cnt=o.cnt))
+    engine.loop_set(loops)
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 320, 5)
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 30, 5, done=320)
+
+
+def test_closed_loop_tie_in_the_top_binade_state(gc, orc, engine):
+    """The single state on which the round-2 closed-loop kernel stalled (tools/debug/loop_hang3.py): a chip step
+    that is a rounding tie in the code's top binade, so the period step falls back to the general walkers, and a
+    carrier phase of -5794 rad (one piece per period).  Four periods against the oracle."""
+    rng = np.random.default_rng(1)
+    n = 16368 * 8
+    data = rng.integers(-60, 61, size=(n, 2), dtype=np.int8)
+    engine.ring_create(1, 2, n)
+    engine.ring_push_raw(1, data, n)
+    engine.set_channels([gc.Channel(32, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)])
+    st = dict(carrfreq=-3560.0113868445246, codefreq=1022997.1414221136, remcode=-0.045902522978210625,
+              remcarr=-5793.900519752811, buffloc=5000)
+    engine.trk_set_state([st])
+    engine.loop_set([engine.loop_state(0, -3600.0)])
+    o = orc.make_chan(32, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+    o.acq.acqfreq = -3600.0
+    o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
+    o.flagsync, o.synci, o.cnt = 0, 0, 0
+    ring = orc.make_ring(data, n, n)
+    _check_against_oracle(orc, engine, [o], ring, [C.c_uint64(5000)], 4, 5)
