@@ -336,25 +336,44 @@ def main():
     # ---- closed loop (pll/dll on the device), same channels ----------------
     if world == 1 and args.loop_periods > 0:
         NP = args.loop_periods
-        cl = {"periods": NP, "channels": NCH, "note": "gnsscorr_trk_run_loop: plan, correlate, cumsumcorr, pll/dll per "
-              "period on the device, one workgroup per channel; no host round trip inside a run"}
-        for name, flagsync in (("loop1_before_bit_sync", 0), ("loop10_after_bit_sync", 1)):
+        cl = {"periods": NP, "channels": NCH, "note": "gnsscorr_trk_run_loop: a chain of launch pairs per filter interval "
+              "(1 period before nav bit sync, 10 after) -- trk_step_tail closes the interval (sums, sdrnavigation's bit sync, "
+              "cumsumcorr, pll/dll) and plans the next, trk_step_corr correlates it (one workgroup per round); no host round "
+              "trip inside a run"}
+        # (loop1: cnt = 0, so that checksync() -- which starts at cnt > 2000, ref src/sdrnav.c:30 -- cannot synchronise a
+        # channel inside the leg; loop10: synchronised from the start)
+        for name, flagsync, cnt0 in (("loop1_before_bit_sync", 0, 0), ("loop10_after_bit_sync", 1, 2001)):
             log(f"closed loop leg: {name}, {NP} periods")
+            lstates = [eng.loop_state(i, 200.0 * round(states0[i]["carrfreq"] / 200.0), flagsync=flagsync,
+                                      synci=(7 * i) % 20, cnt=cnt0) for i in range(NCH)]
             eng.trk_set_state([dict(s, buffloc=s["buffloc"] % NSAMP) for s in states0])
-            eng.loop_set([eng.loop_state(i, 200.0 * round(states0[i]["carrfreq"] / 200.0), flagsync=flagsync,
-                                         synci=(7 * i) % 20, cnt=2001) for i in range(NCH)])
+            eng.loop_set(lstates)
             eng.trk_run_loop(NP)            # warm-up
             eng.sync()
             eng.trk_set_state([dict(s, buffloc=s["buffloc"] % NSAMP) for s in states0])
+            eng.loop_set(lstates)
             barrier()
             t0 = time.perf_counter()
             eng.trk_run_loop(NP)
             eng.sync()
             cdt = time.perf_counter() - t0
-            _, ndone = eng.trk_fetch_log()
+            lg, ndone = eng.trk_fetch_log()
             assert int(ndone.min()) == NP, ndone
+            nupd = int((lg["flagloopfilter"] != 0).sum())
+            # kernel times of the same leg (events around every launch: not part of the figure above)
+            eng.trk_set_state([dict(s, buffloc=s["buffloc"] % NSAMP) for s in states0])
+            eng.loop_set(lstates)
+            eng.timing_reset()
+            eng.timing(1)
+            eng.trk_run_loop(min(NP, 100))
+            eng.sync()
+            eng.timing(False)
+            tt, tn = eng.timing_read("trk_step_tail")
+            tc, tcn = eng.timing_read("trk_step_corr")
             cl[name] = {"x_realtime": NP / cdt / 1000.0, "us_per_period": cdt / NP * 1e6,
-                        "correlations_per_s": NCH * NP * ntap / cdt}
+                        "correlations_per_s": NCH * NP * ntap / cdt, "filter_updates": nupd,
+                        "kernels_us_per_launch": {"trk_step_tail": tt / max(tn, 1) * 1e3, "trk_step_corr": tc / max(tcn, 1) * 1e3,
+                                                  "launch_pairs": tcn}}
         out["closed_loop"] = cl
 
     # ---- host-fed leg: the IF stream comes from host memory (gnsscorr_ring_push: pinned double buffer and

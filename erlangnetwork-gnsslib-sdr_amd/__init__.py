@@ -60,14 +60,17 @@ class LoopState(C.Structure):
                 [(n, C.c_int) for n in ("ne", "nl", "loopms", "rate", "flagsync", "synci", "navcnt", "swloop")] +
                 [("cnt", C.c_uint64)] +
                 [(n, C.c_double) for n in ("carrNco", "codeNco", "carrErr", "codeErr", "freqErr")] +
-                [(n, C.c_double * MAXTAPS) for n in ("II", "QQ", "oldI", "oldQ", "sumI", "sumQ", "oldsumI", "oldsumQ")])
+                [(n, C.c_double * MAXTAPS) for n in ("II", "QQ", "oldI", "oldQ", "sumI", "sumQ", "oldsumI", "oldsumQ")] +
+                [(n, C.c_int) for n in ("prn", "biti", "bit", "swsync", "swreset", "flagpol")] +
+                [("bitIP", C.c_double), ("bitsync", C.c_int * 20)])
 
 
 class TrkLog(C.Structure):
     """gnsscorr_trklog_t: one row per code period of a closed-loop run."""
     _fields_ = ([(n, C.c_double) for n in ("carrfreq", "codefreq", "carrErr", "codeErr", "carrNco", "codeNco", "freqErr",
                                             "remcode", "remcarr")] +
-                [("buffloc", C.c_uint64), ("currnsamp", C.c_int), ("flagloopfilter", C.c_int)])
+                [("buffloc", C.c_uint64), ("currnsamp", C.c_int), ("flagloopfilter", C.c_int), ("flagsync", C.c_int),
+                 ("navbit", C.c_int)])
 
 
 class AcqRes(C.Structure):
@@ -437,6 +440,7 @@ class Engine:
         ls.loopms = loop * int(c.ctime * 1000)
         ls.rate = 10 if c.ctype == CTYPE_G1 else (2 if c.ctype == CTYPE_L1SBAS else 20)
         ls.flagsync, ls.synci, ls.cnt = flagsync, synci, cnt
+        ls.prn = c.prn
         return ls
 
     def loop_set(self, states, ch0=0):

@@ -80,6 +80,12 @@ static void free_channels(gnsscorr_ctx *ctx)
     hipFree(ctx->dloop); ctx->dloop = nullptr;
     hipFree(ctx->dloopdone); ctx->dloopdone = nullptr;
     hipFree(ctx->dlooplog); ctx->dlooplog = nullptr;
+    hipFree(ctx->dstep_meta); ctx->dstep_meta = nullptr;
+    hipFree(ctx->dstep_unit); ctx->dstep_unit = nullptr;
+    hipFree(ctx->dstep_segs); ctx->dstep_segs = nullptr;
+    hipFree(ctx->dstep_rounds); ctx->dstep_rounds = nullptr;
+    hipFree(ctx->dstep_partial); ctx->dstep_partial = nullptr;
+    ctx->step_nseg = 0;
     ctx->looplog_cap = 0;
     ctx->last_loop_nper = 0;
     ctx->state_cur = 0;
@@ -789,13 +795,17 @@ extern "C" int gnsscorr_loop_set(gnsscorr_ctx *ctx, int ch0, int nch, const gnss
         const int ntap = ctx->hchan[ch0 + i].ntap;
         if (l.ne < 0 || l.ne >= ntap || l.nl < 0 || l.nl >= ntap)
             return gc_fail(GNSSCORR_EINVAL, "loop_set: channel %d: early/late tap index %d/%d of %d taps", ch0 + i, l.ne, l.nl, ntap);
-        if (l.loopms < 1 || l.rate < 1)
-            return gc_fail(GNSSCORR_EINVAL, "loop_set: channel %d: loopms %d, rate %d", ch0 + i, l.loopms, l.rate);
+        if (l.loopms < 1 || l.rate < 1 || l.rate > 20)
+            return gc_fail(GNSSCORR_EINVAL, "loop_set: channel %d: loopms %d, rate %d (rate 1..20)", ch0 + i, l.loopms, l.rate);
     }
     GC_HIP(hipSetDevice(ctx->device));
     { int rc = loop_quiesce(ctx); if (rc) return rc; }
     GC_HIP(hipMemcpyAsync(ctx->dloop + ch0, lp, sizeof(gnsscorr_loop_t) * nch, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nch; i++) {
+        if (lp[i].loopms > ctx->loop_kmax) ctx->loop_kmax = lp[i].loopms < GC_STEP_KMAX ? lp[i].loopms : GC_STEP_KMAX;
+        if (lp[i].flagsync) ctx->loop_sync_hint = true;
+    }
     return GNSSCORR_OK;
 }
 
@@ -810,6 +820,30 @@ extern "C" int gnsscorr_loop_get(gnsscorr_ctx *ctx, int ch0, int nch, gnsscorr_l
     return GNSSCORR_OK;
 }
 
+// the step buffers: one filter interval (GC_STEP_KMAX periods at most) per channel
+static int ensure_step_buffers(gnsscorr_ctx *ctx)
+{
+    if (ctx->dstep_meta) return GNSSCORR_OK;
+    int nseg = 1;
+    for (int i = 0; i < ctx->nch; i++) {
+        const int s = gc_step_nseg(ctx->hchan[i].dtype, ctx->max_n);
+        if (s > nseg) nseg = s;
+    }
+    if (nseg > 64) return gc_fail(GNSSCORR_EINVAL, "trk_run_loop: period of %d samples too long (%d rounds, 64 at most)", ctx->max_n, nseg);
+    const size_t units = (size_t)ctx->nch * GC_STEP_KMAX;
+    GC_HIP(hipMalloc((void **)&ctx->dstep_meta, sizeof(GcStepMeta) * ctx->nch));
+    GC_HIP(hipMalloc((void **)&ctx->dstep_unit, sizeof(GcTrkUnit) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dstep_segs, sizeof(GcUnitSegs) * units));
+    GC_HIP(hipMalloc((void **)&ctx->dstep_rounds, sizeof(GcRound) * units * nseg));
+    GC_HIP(hipMalloc((void **)&ctx->dstep_partial, sizeof(int) * units * nseg * 2 * ctx->ntap));
+    if (!ctx->hostflags) {
+        GC_HIP(hipHostMalloc((void **)&ctx->hostflags, 64, hipHostMallocMapped));
+        GC_HIP(hipHostGetDevicePointer((void **)&ctx->hostflags_dev, ctx->hostflags, 0));
+    }
+    ctx->step_nseg = nseg;
+    return GNSSCORR_OK;
+}
+
 extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
 {
     if (!ctx || nperiod <= 0) return gc_fail(GNSSCORR_EINVAL, "trk_run_loop: nperiod %d", nperiod);
@@ -817,7 +851,7 @@ extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
     GC_HIP(hipSetDevice(ctx->device));
     int rc = ensure_trk_buffers(ctx, nperiod);
     if (rc) return rc;
-    rc = gc_ingest_fence(ctx);
+    rc = ensure_step_buffers(ctx);
     if (rc) return rc;
     // the look-ahead planner of the batched interface works on the same state: stop it, drop its plan
     if (ctx->ahead_valid || ctx->fin_pending[0] || ctx->fin_pending[1]) { rc = loop_quiesce(ctx); if (rc) return rc; }
@@ -834,25 +868,73 @@ extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
     GC_HIP(hipMemsetAsync(ctx->dcorrI, 0, sizeof(double) * units * ctx->ntap, ctx->stream));
     GC_HIP(hipMemsetAsync(ctx->dcorrQ, 0, sizeof(double) * units * ctx->ntap, ctx->stream));
     GC_HIP(hipMemsetAsync(ctx->dnsamp2[0], 0, sizeof(int) * units, ctx->stream));
-    // write position of each channel's ring (ref src/sdrtrk.c:26-28: fendbuffsize*buffcnt)
+    GC_HIP(hipMemsetAsync(ctx->dstep_meta, 0, sizeof(GcStepMeta) * ctx->nch, ctx->stream));
+    // write position of each channel's ring (ref src/sdrtrk.c:26-28: fendbuffsize*buffcnt), read together with the
+    // ingest fence under the lock: the positions cover only samples whose transfer the compute stream is ordered behind
     std::vector<uint64_t> wp(ctx->nch);
     {
         std::lock_guard<std::mutex> lk(ctx->mtx);
         for (int i = 0; i < ctx->nch; i++) wp[i] = ctx->ring[ctx->hdesc[i].ftype - 1].wrpos;
+        rc = gc_ingest_fence(ctx);
+        if (rc) return rc;
     }
     uint64_t *dwp = reinterpret_cast<uint64_t *>(ctx->dloopdone + ctx->nch + (ctx->nch & 1));
     GC_HIP(hipMemcpyAsync(dwp, wp.data(), sizeof(uint64_t) * ctx->nch, hipMemcpyHostToDevice, ctx->stream));
-    GC_HIP(hipStreamSynchronize(ctx->stream));          // (wp is a local)
+    GC_HIP(hipStreamSynchronize(ctx->stream));          // (wp is a local; the flags below are host memory)
+    ctx->hostflags[0] = 0;
+    ctx->hostflags[1] = ctx->loop_sync_hint ? 1u : 0u;     // (some channel is known to be synchronised: steps of loopms periods from the start)
     bool have[3] = {false, false, false};
     for (int i = 0; i < ctx->nch; i++) have[ctx->hchan[i].dtype] = true;
-    for (int dtype = 1; dtype <= 2; dtype++) {
-        if (!have[dtype]) continue;
-        GcTimed t(ctx, "trk_loop");
-        rc = gc_launch_trk_loop(ctx->stream, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dloop, dwp, ctx->dcorrI, ctx->dcorrQ,
-                                ctx->dnsamp2[0], ctx->dlooplog, ctx->dloopdone, ctx->dnco_overflow, ctx->nch, nperiod, ctx->nseg,
-                                dtype, ctx->ntap, ctx->max_n, ctx->smax_max);
-        if (rc) return rc;
+    // One step = tail (close the previous interval, plan the next) + correlator.  Every step advances every channel
+    // that still has work by at least one period, so nperiod steps always suffice; channels whose nav bit is
+    // synchronised advance by up to loopms periods per step.  The host keeps a bounded number of steps ahead of the
+    // device and stops as soon as the device says every channel is done (a pinned word the tail kernel updates).
+    const int kmax = ctx->loop_kmax < 1 ? 1 : ctx->loop_kmax;
+    const int BURST = 8, AHEAD = 3;
+    hipEvent_t ev[AHEAD] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < AHEAD; i++) GC_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    auto cleanup = [&]() { for (int i = 0; i < AHEAD; i++) if (ev[i]) hipEventDestroy(ev[i]); };
+    int steps = 0, burst = 0;
+    bool done = false;
+    while (!done && steps <= nperiod) {
+        if (burst >= AHEAD) {                           // at most AHEAD bursts in flight
+            hipError_t e = hipEventSynchronize(ev[burst % AHEAD]);
+            if (e != hipSuccess) { cleanup(); return gc_fail_hip(e, "hipEventSynchronize", __FILE__, __LINE__); }
+            if (ctx->hostflags[0] >= (unsigned)ctx->nch) break;
+        }
+        for (int b = 0; b < BURST && steps <= nperiod; b++, steps++) {
+            // periods per step: 1 while no channel is synchronised (a performance hint only: the tail never plans more
+            // than kcap periods, and any kcap >= 1 is correct)
+            const int kcap = ctx->hostflags[1] ? kmax : 1;
+            {
+                GcTimed t(ctx, "trk_step_tail");
+                rc = gc_launch_step_tail(ctx->stream, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dloop, ctx->dstep_meta, dwp,
+                                         ctx->dstep_partial, ctx->dstep_unit, ctx->dstep_segs, ctx->dstep_rounds, ctx->dcorrI,
+                                         ctx->dcorrQ, ctx->dnsamp2[0], ctx->dlooplog, ctx->dloopdone, ctx->dnco_overflow,
+                                         ctx->hostflags_dev, ctx->nch, nperiod, ctx->step_nseg, ctx->ntap, ctx->max_n, kcap, 1);
+                if (rc) { cleanup(); return rc; }
+            }
+            for (int dtype = 1; dtype <= 2; dtype++) {
+                if (!have[dtype]) continue;
+                GcTimed t(ctx, "trk_step_corr");
+                rc = gc_launch_step_corr(ctx->stream, ctx->dchan, ctx->dstep_meta, ctx->dstep_unit, ctx->dstep_segs, ctx->dstep_rounds,
+                                         ctx->dstep_partial, ctx->nch, kcap, ctx->step_nseg, dtype, ctx->ntap, ctx->max_n,
+                                         ctx->smax_max);
+                if (rc) { cleanup(); return rc; }
+            }
+        }
+        hipError_t e = hipEventRecord(ev[burst % AHEAD], ctx->stream);
+        if (e != hipSuccess) { cleanup(); return gc_fail_hip(e, "hipEventRecord", __FILE__, __LINE__); }
+        burst++;
     }
+    // close whatever the last correlator launch produced
+    rc = gc_launch_step_tail(ctx->stream, ctx->dchan, ctx->dstate2[ctx->state_cur], ctx->dloop, ctx->dstep_meta, dwp, ctx->dstep_partial,
+                             ctx->dstep_unit, ctx->dstep_segs, ctx->dstep_rounds, ctx->dcorrI, ctx->dcorrQ, ctx->dnsamp2[0],
+                             ctx->dlooplog, ctx->dloopdone, ctx->dnco_overflow, ctx->hostflags_dev, ctx->nch, nperiod, ctx->step_nseg,
+                             ctx->ntap, ctx->max_n, 1, 0);
+    cleanup();
+    if (rc) return rc;
+    if (ctx->hostflags[1]) ctx->loop_sync_hint = true;
     ctx->last_slot = 0;
     ctx->fin_pending[0] = ctx->fin_pending[1] = false;
     ctx->last_nepoch = nperiod;

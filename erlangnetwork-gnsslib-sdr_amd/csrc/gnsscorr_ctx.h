@@ -88,10 +88,19 @@ struct gnsscorr_ctx {
     GcUnitSegs *dsegs2[2] = {nullptr, nullptr};    // [unit]: the unit's carrier / code NCO piece tables
     int *dnco_overflow = nullptr;
     int *dring_viol = nullptr;                     // planned periods outside what the ring holds, since the last fetch
-    // closed loop (gnsscorr_trk_run_loop): per channel loop state, NCO tables of the period at hand,
-    // one log row per period
+    // closed loop (gnsscorr_trk_run_loop): per channel loop state, one log row per period; the step buffers hold one
+    // filter interval per channel (GC_STEP_KMAX periods at most): unit constants, NCO tables, rounds, partial sums
     gnsscorr_loop_t *dloop = nullptr;              // [nch]
-    GcUnitSegs *dloopsegs = nullptr;               // [nch]
+    GcStepMeta *dstep_meta = nullptr;              // [nch]
+    GcTrkUnit *dstep_unit = nullptr;               // [nch][GC_STEP_KMAX]
+    GcUnitSegs *dstep_segs = nullptr;
+    GcRound *dstep_rounds = nullptr;               // [nch][GC_STEP_KMAX][step_nseg]
+    int *dstep_partial = nullptr;                  // [nch][GC_STEP_KMAX][step_nseg][2*ntap]
+    int step_nseg = 0;
+    unsigned *hostflags = nullptr;                 // pinned, device-visible: [0] channels whose run is over, [1] some channel has its nav bit synchronised
+    unsigned *hostflags_dev = nullptr;
+    bool loop_sync_hint = false;                   // some channel had its nav bit synchronised when last seen
+    int loop_kmax = 1;                             // largest loopms among the channels' loop states (gnsscorr_loop_set)
     gnsscorr_trklog_t *dlooplog = nullptr;         // [nch][looplog_cap]
     int *dloopdone = nullptr;                      // [nch]
     size_t looplog_cap = 0;

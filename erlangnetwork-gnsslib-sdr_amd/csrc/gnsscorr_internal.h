@@ -151,6 +151,27 @@ int gc_launch_trk_finish(hipStream_t st, const int *partial, double *corrI, doub
 int gc_trk_nseg(int dtype, int max_n);
 int gc_launch_trk_ringcheck(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, const int8_t *ring0, uint64_t wrpos0,
                             uint64_t wrpos1, int nch, int nepoch, int *viol);
-int gc_launch_trk_loop(hipStream_t st, const GcChan *chan, GcTrkState *state, gnsscorr_loop_t *loop, const uint64_t *wrpos,
-                       double *corrI, double *corrQ, int *nsamp_out, gnsscorr_trklog_t *log, int *ndone, int *nco_overflow,
-                       int nch, int nper, int nseg, int dtype, int ntap, int max_n, int smax_max);
+
+// ---- closed loop in steps (gnsscorr_loop.hip) ---------------------------------------------------------------
+// One step = one filter interval per channel: the periods up to and including the next one after which pll()/dll()
+// run (1 before the nav bit is synchronised; afterwards up to loopms, counted from the bit edge).
+#define GC_STEP_KMAX 20         // periods per step and channel, at most
+struct GcStepMeta {             // per channel, device resident
+    int k;                      // periods planned for the correlator launch that follows (0: none)
+    int kcap;                   // unit stride of that plan (the kcap of the launch that planned it)
+    int pbase;                  // index, within the run, of the interval's first period
+    int done;                   // periods planned so far in this run
+    int consumed;               // periods closed (sums, nav bit, filters, log) so far in this run
+    int finished;               // the run is over for this channel (all periods closed, or the ring has no more data)
+    int early;                  // (diagnostic) a filter update fell inside an interval: must stay 0
+    int pad;
+};
+int gc_step_nseg(int dtype, int max_n);          // workgroups (one round each) per period
+// closes the intervals the previous correlator launch produced and plans the next ones (plan = 0: closes only)
+int gc_launch_step_tail(hipStream_t st, const GcChan *chan, GcTrkState *state, gnsscorr_loop_t *loop, GcStepMeta *meta,
+                        const uint64_t *wrpos, const int *partial, GcTrkUnit *unit, GcUnitSegs *segs, GcRound *rounds,
+                        double *corrI, double *corrQ, int *nsamp_out, gnsscorr_trklog_t *log, int *ndone, int *nco_overflow,
+                        unsigned *hostflags, int nch, int nper, int nseg, int ntap, int max_n, int kcap, int plan);
+int gc_launch_step_corr(hipStream_t st, const GcChan *chan, const GcStepMeta *meta, const GcTrkUnit *unit, const GcUnitSegs *segs,
+                        const GcRound *rounds, int *partial, int nch, int kcap, int nseg, int dtype, int ntap, int max_n,
+                        int smax_max);

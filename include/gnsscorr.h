@@ -158,10 +158,13 @@ int  gnsscorr_trk_devptrs(gnsscorr_ctx *ctx, void **trkII, void **trkQQ);
  * src/sdrtrk.c:64-76), run the loop filters -- every period with prm1 until the
  * nav bit is synchronised, then whenever checkbit() raises swloop (every loopms
  * periods counted from the bit edge, ref src/sdrnav.c:241-262) with prm2 -- and
- * clear the sums after each filter update.  The loop state lives on the device
- * next to the NCO state; a run of N periods needs no host round trip.
- * Bit synchronisation itself (checksync(), ref src/sdrnav.c:198-233) stays with
- * the caller's nav module: it reports flagsync/synci through gnsscorr_loop_set. */
+ * clear the sums after each filter update.  Bit synchronisation (checksync(),
+ * ref src/sdrnav.c:198-233) and the bit decisions of checkbit() run on the
+ * device too, so a channel goes acquisition -> loop every period -> flagsync ->
+ * loop every loopms periods without the host.  The loop state lives on the
+ * device next to the NCO state; a run of N periods needs no host round trip:
+ * it is a chain of launches -- per filter interval one that closes the interval
+ * (sums, nav bit, filters) and plans the next, and one that correlates it. */
 typedef struct {
     double acqfreq;                         /* ref sdracq_t.acqfreq                   */
     double f_if, foffset, f_cf, crate, ctime;   /* ref sdrch_t                        */
@@ -178,6 +181,17 @@ typedef struct {
     double oldI[GNSSCORR_MAXTAPS], oldQ[GNSSCORR_MAXTAPS];
     double sumI[GNSSCORR_MAXTAPS], sumQ[GNSSCORR_MAXTAPS];
     double oldsumI[GNSSCORR_MAXTAPS], oldsumQ[GNSSCORR_MAXTAPS];
+    /* navigation bit synchronisation: the part of sdrnavigation() that schedules the loops (ref
+     * src/sdrnav.c:18-36: biti, checksync() :198-233, checkbit() :241-282), run on the device after
+     * every period's correlator like the reference does from sdrtracking() (ref src/sdrtrk.c:46) */
+    int    prn;                             /* ref sdrnav_t.sdreph.prn (= the channel's PRN, src/sdrinit.c:506):
+                                               checksync() takes its sign shift-register branch for prn > 5 (:203) */
+    int    biti;                            /* ref sdrnav_t.biti                      */
+    int    bit;                             /* ref sdrnav_t.bit: last decided bit, +-1 */
+    int    swsync, swreset;                 /* ref sdrnav_t.swsync / .swreset         */
+    int    flagpol;                         /* ref sdrnav_t.flagpol (the frame decoder's; 0 unless the caller sets it) */
+    double bitIP;                           /* ref sdrnav_t.bitIP                     */
+    int    bitsync[20];                     /* ref sdrnav_t.bitsync[rate], rate <= 20 */
 } gnsscorr_loop_t;
 
 int  gnsscorr_loop_set(gnsscorr_ctx *ctx, int ch0, int nch, const gnsscorr_loop_t *lp);
@@ -191,12 +205,16 @@ typedef struct {
     uint64_t buffloc;                       /* first sample of this period            */
     int    currnsamp;
     int    flagloopfilter;                  /* 0 none, 1 prm1, 2 prm2                 */
+    int    flagsync;                        /* ref sdrnav_t.flagsync after this period */
+    int    navbit;                          /* +-1: checkbit() decided a bit in this period (swsync), else 0 */
 } gnsscorr_trklog_t;
 
 /* Track `nperiod` code periods of every channel closed loop.  A channel stops early
  * where sdrtracking() would find no data yet (ref src/sdrtrk.c:26-30: bufflocnow
- * <= buffloc).  Asynchronous; results by gnsscorr_trk_fetch (II/QQ per period,
- * periods not run are zero with nsamp_out 0) and gnsscorr_trk_fetch_log. */
+ * <= buffloc).  Returns when the last launches are queued (it keeps at most a few
+ * filter intervals of launches ahead of the device); results by gnsscorr_trk_fetch
+ * (II/QQ per period, periods not run are zero with nsamp_out 0) and
+ * gnsscorr_trk_fetch_log. */
 int  gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod);
 /* log[nch][nperiod] of the last gnsscorr_trk_run_loop; ndone[nch] = periods run */
 int  gnsscorr_trk_fetch_log(gnsscorr_ctx *ctx, gnsscorr_trklog_t *log, int *ndone);

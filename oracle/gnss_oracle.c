@@ -523,6 +523,7 @@ int orc_initchan(orc_chan_t *ch, int prn, int ctype, int dtype, double f_cf,
         if (ch->corrp[i] == corrp) { ch->ne = 2 * (i + 1) - 1; ch->nl = 2 * (i + 1); }
     }
     ch->loopms = (ctype == ORC_CTYPE_L1SBAS ? 2 : 10) * (int)(ch->ctime * 1000);
+    ch->prn = prn;                                                                  /* nav->sdreph.prn, ref src/sdrinit.c:506 */
     ch->rate = ctype == ORC_CTYPE_G1 ? 10 : (ctype == ORC_CTYPE_L1SBAS ? 2 : 20);   /* NAVRATE_*, ref src/sdr.h:159-171 */
     for (i = 0; i < 2; i++) {
         ch->dllw2[i] = (dllb[i] / 0.53) * (dllb[i] / 0.53);
@@ -645,20 +646,100 @@ void orc_dll(orc_chan_t *ch, int prm, double dt)
     ch->codeErr = codeErr;
 }
 
-/* ref src/sdrmain.c:264-312 with the timing lines of src/sdrnav.c:18-20 (biti) and :241-262 (checkbit:
- * counter reset at the bit edge, swloop every loopms counts); nav.ocode is all ones (src/sdrinit.c:520-521) */
+/* maxvi(), ref src/sdrcmn.c:407-422 */
+static int orc_maxvi(const int *data, int n, int exinds, int exinde, int *ind)
+{
+    int i, max = data[0];
+    *ind = 0;
+    for (i = 1; i < n; i++) {
+        if ((exinds <= exinde && (i < exinds || i > exinde)) || (exinds > exinde && (i < exinds && i > exinde))) {
+            if (max < data[i]) {
+                max = data[i];
+                *ind = i;
+            }
+        }
+    }
+    return max;
+}
+
+#define ORC_NAVSYNCTH 50    /* ref src/sdr.h:157 */
+
+/* checksync(), ref src/sdrnav.c:198-233.  nav->sdreph.prn is the channel's PRN (ref src/sdrinit.c:506): every PRN
+ * above 5 takes the shift-register branch; nav->ocode is all ones for L1CA / SBAS / G1 (ref src/sdrinit.c:520-521,
+ * 542-543, 557-558). */
+int orc_checksync(double IP, double IPold, orc_chan_t *ch)
+{
+    int i, corr = 0, maxi;
+    if (ch->prn > 5) {
+        /* shiftdata(&bitsync[0], &bitsync[1], sizeof(int), rate-1): ref src/sdrcmn.c:587-596 */
+        memmove(&ch->bitsync[0], &ch->bitsync[1], sizeof(int) * (size_t)(ch->rate - 1));
+        ch->bitsync[ch->rate - 1] = (IP < 0 ? -1 : 1);
+        for (i = 0; i < ch->rate; i++) corr += 1 * ch->bitsync[i];
+        if (abs(corr) == ch->rate) {
+            ch->synci = ch->biti;
+            return 1;
+        }
+    } else {
+        if (IPold * IP < 0) {
+            ch->bitsync[ch->biti] += 1;
+            maxi = orc_maxvi(ch->bitsync, ch->rate, -1, -1, &ch->synci);
+            if (maxi > ORC_NAVSYNCTH) {
+                ch->synci--;
+                if (ch->synci < 0) ch->synci = ch->rate - 1;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* checkbit(), ref src/sdrnav.c:241-282; nav->cnt is navcnt here.  The frame bit buffer (fbits, :272-275) belongs
+ * to the frame decoder, which is outside the path: the decided bit is left in ch->bit / ch->swsync. */
+int orc_checkbit(double IP, int loopms, orc_chan_t *ch)
+{
+    int diffi = ch->biti - ch->synci, syncflag = 1, polarity = 1;
+    ch->swreset = 0;
+    ch->swsync = 0;
+    if (diffi == 1 || diffi == -ch->rate + 1) {
+        ch->bitIP = IP;
+        ch->swreset = 1;
+        ch->navcnt = 1;
+    } else {
+        ch->bitIP += IP;
+        if (ch->bitIP * IP < 0) syncflag = 0;
+    }
+    if (ch->navcnt % loopms == 0) ch->swloop = 1;
+    else ch->swloop = 0;
+    if (diffi == 0) {
+        if (ch->flagpol) polarity = -1;
+        else polarity = 1;
+        ch->bit = (ch->bitIP < 0) ? -polarity : polarity;
+        ch->swsync = 1;
+    }
+    ch->navcnt++;
+    return syncflag;
+}
+
+/* sdrnavigation() up to the frame decoder, ref src/sdrnav.c:18-36 */
+void orc_sdrnavigation_sync(orc_chan_t *ch, uint64_t cnt)
+{
+    ch->biti = (int)(cnt % (uint64_t)ch->rate);
+    if (ch->rate == 1 && cnt > 2000 / (ch->ctime * 1000)) {
+        ch->synci = 0;
+        ch->flagsync = 1;
+    }
+    if (!ch->flagsync && cnt > 2000 / (ch->ctime * 1000))
+        ch->flagsync = orc_checksync(ch->II[0], ch->oldI[0], ch);
+    if (ch->flagsync) orc_checkbit(ch->II[0], ch->loopms, ch);
+}
+
+/* ref src/sdrmain.c:264-312; sdrnavigation() is called from sdrtracking() after the correlator (src/sdrtrk.c:46);
+ * nav.ocode is all ones (src/sdrinit.c:520-521) */
 int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc)
 {
     orc_sdrtracking(ch, ring, *buffloc);
     if (!ch->flagtrk) return 0;
-    /* sdrnavigation() is called from sdrtracking() after the correlator (src/sdrtrk.c:46) */
-    if (ch->flagsync) {
-        int biti = (int)(ch->cnt % (uint64_t)ch->rate);
-        int diffi = biti - ch->synci;
-        if (diffi == 1 || diffi == -ch->rate + 1) ch->navcnt = 1;
-        ch->swloop = (ch->navcnt % ch->loopms == 0);
-        ch->navcnt++;
-    }
+    orc_sdrnavigation_sync(ch, ch->cnt);
     orc_cumsumcorr(ch, 1);
     ch->flagloopfilter = 0;
     if (!ch->flagsync) {

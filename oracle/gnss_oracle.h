@@ -131,6 +131,12 @@ typedef struct {
     /* nav timing that schedules the loop filters (ref src/sdrnav.c:18-31,241-262) + thread counter */
     int    rate, flagsync, synci, navcnt, swloop, flagloopfilter;
     uint64_t cnt;
+    /* navigation bit synchronisation and decision (ref sdrnav_t src/sdr.h:441-480; src/sdrnav.c:18-36,198-282);
+     * navcnt above is sdrnav_t.cnt */
+    int    prn;             /* sdrnav_t.sdreph.prn = the channel's PRN (ref src/sdrinit.c:506) */
+    int    biti, bit, swsync, swreset, flagpol;
+    double bitIP;
+    int    bitsync[20];     /* sdrnav_t.bitsync[rate] */
 } orc_chan_t;
 
 /* ref src/sdrinit.c:583-657 (+ :385-394, :402-480); xcode left NULL */
@@ -147,6 +153,10 @@ uint64_t orc_sdrtracking(orc_chan_t *ch, const orc_ring_t *ring,
 /* ref src/sdrtrk.c:64-86 */
 void orc_cumsumcorr(orc_chan_t *ch, int polarity);
 void orc_clearcumsumcorr(orc_chan_t *ch);
+/* ref src/sdrnav.c:198-233, :241-282 and the part of sdrnavigation() in front of the frame decoder (:18-36) */
+int  orc_checksync(double IP, double IPold, orc_chan_t *ch);
+int  orc_checkbit(double IP, int loopms, orc_chan_t *ch);
+void orc_sdrnavigation_sync(orc_chan_t *ch, uint64_t cnt);
 /* ref src/sdrtrk.c:95-150; prm = 0 (before nav sync) or 1 (after) */
 void orc_pll(orc_chan_t *ch, int prm, double dt);
 void orc_dll(orc_chan_t *ch, int prm, double dt);

@@ -36,7 +36,9 @@ class Chan(C.Structure):
                 [("currnsamp", C.c_int)] +
                 [(n, C.c_double * 2) for n in ("dllw2", "dllaw", "pllw2", "pllaw", "fllw")] +
                 [(n, C.c_int) for n in ("rate", "flagsync", "synci", "navcnt", "swloop", "flagloopfilter")] +
-                [("cnt", C.c_uint64)])
+                [("cnt", C.c_uint64)] +
+                [(n, C.c_int) for n in ("prn", "biti", "bit", "swsync", "swreset", "flagpol")] +
+                [("bitIP", C.c_double), ("bitsync", C.c_int * 20)])
 
 
 _lib = None

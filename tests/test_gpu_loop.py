@@ -35,7 +35,10 @@ FILTER_FIELDS = ("carrfreq", "codefreq", "carrNco", "codeNco", "carrErr", "codeE
 
 def _adopt(o, r, where):
     """This period's filter outputs: equal to the oracle's to a few ulps (same inputs), then the oracle continues
-    from the device's values, so that the next period starts from identical frequencies on both sides."""
+    from the device's values, so that the next period starts from identical frequencies on both sides.  The nav
+    bit synchronisation (flagsync, decided bits) involves no library call: exact."""
+    assert r["flagsync"] == o.flagsync, (where, "flagsync")
+    assert r["navbit"] == (o.bit if (o.flagsync and o.swsync) else 0), (where, "navbit")
     for f in FILTER_FIELDS:
         assert _close(float(r[f]), getattr(o, f)), (where, f, float(r[f]), getattr(o, f))
         setattr(o, f, float(r[f]))
@@ -222,3 +225,50 @@ def test_closed_loop_tie_in_the_top_binade_state(gc, orc, engine):
     o.flagsync, o.synci, o.cnt = 0, 0, 0
     ring = orc.make_ring(data, n, n)
     _check_against_oracle(orc, engine, [o], ring, [C.c_uint64(5000)], 4, 5)
+
+
+def test_closed_loop_bit_sync_on_the_device(gc, orc, synth, engine):
+    """f3: sdrnavigation()'s bit synchronisation and bit decision on the device (ref src/sdrnav.c:18-36,198-282):
+    three satellites with 50 bps data, loops closed every period until checksync() reports the bit edge, then every
+    10 periods counted from it -- acquisition hand-over state to loop-10 without the host.  PRN 3 goes through the
+    vote histogram (more than NAVSYNCTH = 50 sign changes at one position: about 2000 periods), PRN 12 and 25
+    through the sign shift register the fork uses for every PRN above 5.  5200 periods per channel: flagsync
+    period, decided bits, swloop cadence, sums and remainders bit for bit."""
+    prns, dop, cph = [3, 12, 25], [1517.0, -3222.0, 2630.0], [311.3, 12.8, 870.1]
+    nper, NS = 5200, 16368
+    codes = {p: gc.gencode(p, gc.CTYPE_L1CA) for p in prns}
+    rng = np.random.default_rng(5)
+    sats = [dict(prn=p, doppler=d, codephase=c, cn0=50.0, phase=0.3 * i, bits=rng.choice([-1.0, 1.0], size=257))
+            for i, (p, d, c) in enumerate(zip(prns, dop, cph))]
+    sig = synth.make_if(codes, NS * (nper + 3), f_sf=F_SF, f_if=0.0, dtype=2, sats=sats, seed=77)
+    nsamples = sig.shape[0]
+    engine.ring_create(1, 2, nsamples)
+    engine.ring_push_raw(1, sig, nsamples)
+    chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in prns]
+    engine.set_channels(chans)
+    ring = orc.make_ring(sig, nsamples, nsamples)
+    ochs, bufflocs, states, loops = [], [], [], []
+    for i, c in enumerate(chans):
+        acqfreq = 200.0 * round(dop[i] / 200.0)
+        o = orc.make_chan(c.prn, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+        o.acq.acqfreq = acqfreq
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = acqfreq, c.crate, 0.0, 0.0
+        o.flagsync, o.synci, o.cnt = 0, 0, 1990 + i          # checksync() starts once cnt > 2000 (ref src/sdrnav.c:30)
+        b = int(round((1023 - cph[i]) * 16)) % NS
+        ochs.append(o)
+        bufflocs.append(C.c_uint64(b))
+        states.append(dict(carrfreq=acqfreq, codefreq=c.crate, remcode=0.0, remcarr=0.0, buffloc=b))
+        loops.append(engine.loop_state(i, acqfreq, flagsync=0, synci=0, cnt=o.cnt))
+    engine.trk_set_state(states)
+    engine.loop_set(loops)
+    done = 0
+    for nrun in (1500, 1700, 2000):
+        _check_against_oracle(orc, engine, ochs, ring, bufflocs, nrun, 5, done=done)
+        done += nrun
+    lst = engine.loop_get()
+    for i, o in enumerate(ochs):
+        assert o.flagsync == 1 and lst[i].flagsync == 1, i             # every channel found its bit edge ...
+        for f in ("synci", "biti", "navcnt", "swloop", "bit", "swsync", "swreset", "bitIP", "cnt"):
+            assert getattr(lst[i], f) == getattr(o, f), (i, f)
+        assert list(lst[i].bitsync) == list(o.bitsync), i
+        assert abs(o.carrfreq - dop[i]) < 30.0, (i, o.carrfreq)       # ... and the loops stayed locked on it
