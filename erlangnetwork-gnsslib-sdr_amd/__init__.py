@@ -49,8 +49,6 @@ class TrkState(C.Structure):
                 ("remcarr", C.c_double), ("buffloc", C.c_uint64)]
 
 
-MAXTAPS = 33
-FMT_STEREO, FMT_RTLSDR = 1, 2
 
 
 class LoopState(C.Structure):
@@ -344,6 +342,10 @@ class Engine:
     @property
     def stream(self):
         return self._L.gnsscorr_stream(self.h)
+
+    def stream_ptr(self):
+        """The context's HIP stream as an integer (for torch.cuda.ExternalStream)."""
+        return int(self._L.gnsscorr_stream(self.h) or 0)
 
     def sync(self):
         _check(self._L.gnsscorr_sync(self.h))

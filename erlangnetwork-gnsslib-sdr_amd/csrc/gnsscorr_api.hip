@@ -638,8 +638,16 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipSetDevice(ctx->device));
     int rc = ensure_trk_buffers(ctx, nepoch);
     if (rc) return rc;
-    rc = gc_ingest_fence(ctx);
-    if (rc) return rc;
+    // the rings' write positions and the ingest fence together, under the lock (a grabber thread may be pushing): the
+    // positions handed to the ring check cover only samples whose transfer the compute stream is ordered behind
+    uint64_t wr0, wr1;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        wr0 = ctx->ring[0].wrpos;
+        wr1 = ctx->ring[1].wrpos;
+        rc = gc_ingest_fence(ctx);
+        if (rc) return rc;
+    }
     // ---- planner: use the look-ahead plan if it matches, else plan now ----
     // plan = the sequential NCO chain per channel (discovery pass + chain), on the planner stream into the
     // slot's plan buffer; ev_plan[slot] marks it ready
@@ -712,12 +720,6 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
     }
     // the planned periods against what the rings hold now
     // (the write positions travel as kernel arguments: no copy, no host synchronisation per batch)
-    uint64_t wr0, wr1;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mtx);       // (a grabber thread may be pushing)
-        wr0 = ctx->ring[0].wrpos;
-        wr1 = ctx->ring[1].wrpos;
-    }
     rc = gc_launch_trk_ringcheck(ctx->stream, ctx->dchan, ctx->dplan2[slot], (const int8_t *)ctx->ring[0].mem, wr0, wr1, ctx->nch,
                                  nepoch, ctx->dring_viol);
     if (rc) return rc;

@@ -55,8 +55,20 @@ static void host_rems(double phi0, double freq, double ti, int n, double coff, i
 {
     GcNoEmit ne;
     *remp = gc_carrier_prem(gc_carrier_walk(gc_carrier_phis(phi0), gc_carrier_ps(freq, ti), n, ne));
-    if (ci > 0.0 && ci < (double)len)
+    if (ci > 0.0 && ci < (double)len) {
         *remc = gc_code_rem(gc_code_walk(gc_code_start(coff, smax, ci, len), ci, len, n + 2 * smax, ne), smax, ci);
+    } else {
+        // a chip step outside (0, len): the reference's table reads are out of bounds there (nothing is correlated), but
+        // rescode() still returns a remainder -- its own loop, literally (ref src/sdrcmn.c:613-620)
+        GC_FP_STRICT
+        const double dlen = (double)len;
+        double c = gc_code_start(coff, smax, ci, len);
+        for (int i = 0; i < n + 2 * smax; i++) {
+            if (c >= dlen) c = c - dlen;
+            c = c + ci;
+        }
+        *remc = gc_code_rem(c, smax, ci);
+    }
 }
 
 // One (channel, period) unit on samples that already sit in a device ring.
@@ -185,7 +197,7 @@ struct TrkReq {
     char err[200];
 };
 
-struct CodeSlot { int8_t *dcode = nullptr; long sum = -1; int clen = 0, nedge = 0, pm1 = 0; };
+struct CodeSlot { int8_t *dcode = nullptr; unsigned long sum = ~0ul; int clen = 0, nedge = 0, pm1 = 0; };
 
 struct TrkCombiner {
     std::mutex qm;
@@ -211,9 +223,13 @@ int cmb_reserve(gnsscorr_ctx *ctx, int k, int nseg, int ntap)
     TrkCombiner &q = g_cmb;
     if (k <= q.cap && nseg <= q.nseg_cap && ntap <= q.ntap_cap) return 0;
     GC_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(q.dchan); hipFree(q.dplan); hipFree(q.dunit); hipFree(q.dsegs); hipFree(q.drounds); hipFree(q.dpartial);
-    hipFree(q.dout); hipFree(q.dfinish); hipFree(q.doverflow);
-    hipHostFree(q.hchan); hipHostFree(q.hplan); hipHostFree(q.hout);
+    // (every pointer is cleared as it is freed: an allocation that fails below leaves nothing dangling, and the next
+    // call -- capacities are zero -- starts over)
+    auto dfree = [](auto *&p) { if (p) hipFree(p); p = nullptr; };
+    auto hfree = [](auto *&p) { if (p) hipHostFree(p); p = nullptr; };
+    dfree(q.dchan); dfree(q.dplan); dfree(q.dunit); dfree(q.dsegs); dfree(q.drounds); dfree(q.dpartial);
+    dfree(q.dout); dfree(q.dfinish); dfree(q.doverflow);
+    hfree(q.hchan); hfree(q.hplan); hfree(q.hout);
     const int cap = k > 64 ? k : 64, ns = nseg > 1 ? nseg : 1, nt = GNSSCORR_MAXTAPS;
     q.cap = q.nseg_cap = q.ntap_cap = 0;
     GC_HIP(hipMalloc((void **)&q.dchan, sizeof(GcChan) * cap));
@@ -237,9 +253,15 @@ int cmb_reserve(gnsscorr_ctx *ctx, int k, int nseg, int ntap)
 // the channel's code block on the device (uploaded when the code of this sdrch_t is first seen or changes)
 int cmb_code(gnsscorr_ctx *ctx, sdrch_t *sdr, CodeSlot **out)
 {
+    // (keyed by the caller's sdrch_t: a receiver has at most MAXSAT of them; a caller that keeps handing in new structs
+    // gets the table emptied instead of growing without bound -- the stream is idle here, every call ends synchronised)
+    if (g_cmb.codes.size() > 256 && !g_cmb.codes.count(sdr)) {
+        for (auto &kv : g_cmb.codes) if (kv.second.dcode) hipFree(kv.second.dcode);
+        g_cmb.codes.clear();
+    }
     CodeSlot &cs = g_cmb.codes[sdr];
-    long sum = 0;
-    for (int i = 0; i < sdr->clen; i++) sum = sum * 31 + sdr->code[i];
+    unsigned long sum = 0;          // (unsigned: the hash wraps)
+    for (int i = 0; i < sdr->clen; i++) sum = sum * 31u + (unsigned long)(unsigned short)sdr->code[i];
     if (!cs.dcode || cs.sum != sum || cs.clen != sdr->clen) {
         if (!cs.dcode) GC_HIP(hipMalloc((void **)&cs.dcode, GC_CODEBLOCK));
         int8_t block[GC_CODEBLOCK];

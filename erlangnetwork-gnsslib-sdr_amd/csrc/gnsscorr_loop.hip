@@ -357,7 +357,7 @@ __device__ __attribute__((noinline)) double tail_code_slow(double ci, double rem
     return gc_code_rem(cend, smax, ci);
 }
 
-#define GC_TAIL_NW 8            // wavefronts of the tail workgroup
+#define GC_TAIL_NW 16           // wavefronts of the tail workgroup
 struct TailShared {
     gnsscorr_loop_t lp;
     GcTrkState st;                                  // the channel's state while the kernel runs (frequencies: wavefront 0)
@@ -541,10 +541,11 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
         // step tables of the interval's two frequencies, one lane per binade
         if (wave == 0) {
             fast_init_lanes(S.PK.f, ps, false, lane);
-            fast_init_lanes(S.PK.fprem, -GC_NCO_DPI, true, lane);
             if (lane == 0) S.PK.ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
         } else if (wave == 1) {
             code_plan_init_lanes(S.PC, ci, c.clen, c.smax, lane);
+        } else if (wave == 2) {
+            fast_init_lanes(S.PK.fprem, -GC_NCO_DPI, true, lane);
         }
     }
     __syncthreads();
@@ -588,41 +589,71 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
         const uint64_t bufflocnow = wp - (uint64_t)c.nsamp;
         if (wave == 1) {
             // period starts: is the period there yet (ref src/sdrtrk.c:26-30), its length (:31-32), and -- for an interval of
-            // several periods -- the code chain (nothing emitted)
-            double remcode = S.remcode[0];
-            uint64_t buffloc = S.buffloc[0];
-            GcNoEmit ne;
-            int k = 0;
-            for (int e = 0; e < want; e++) {
-                if (!(have_data && bufflocnow > buffloc)) { if (lane == 0) S.starved = 1; break; }
-                const double q = __ddiv_rn(__dsub_rn(dlen, remcode), spc);
-                const int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
-                const bool valid = n > 0 && n <= max_n && shape_ok;
-                if (lane == 0) {
-                    S.n[e] = n;
-                    S.valid[e] = valid ? 1 : 0;
-                    S.remcode[e] = remcode;
-                    S.buffloc[e] = buffloc;
-                }
-                k = e + 1;
-                if (want > 1) {
-                    tail_wave_sync();
-                    if (lane == 0) __hip_atomic_store(&S.prog, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (valid) {
-                        double r;
-                        GcCodeClaims cl = S.ccl[e];
-                        if (gc_code_claims<false>(S.PC, remcode, n + 2 * c.smax, cl, &r)) remcode = r;
-                        else if (gc_code_period(S.PC, remcode, n + 2 * c.smax, fill, &r, ne)) remcode = r;
-                        else remcode = tail_code_slow(ci, remcode, c.clen, c.smax, n + 2 * c.smax, ne);
+            // several periods -- the code chain (nothing emitted).  One instance per shape of the code step (the table binade
+            // that holds the code length), so that the step's constants stay in registers over the interval.
+            auto code_chain = [&](auto itop_tag) {
+                constexpr int ITOP = decltype(itop_tag)::value;       // (0: no instance: the certified step serves the channel)
+                constexpr int IT = ITOP ? ITOP : 7;
+                GcCodeStepC<IT> SC;
+                const bool inst = ITOP != 0 && S.PC.ok;
+                if (inst) gc_code_stepc_init(SC, S.PC);
+                const int tcls = c.smax + 1 > 8 ? (c.smax + 1 > GC_CLAIM_TAIL ? 2 : 1) : 0;       // tail positions: 8, 15 or 32
+                double remcode = S.remcode[0];
+                uint64_t buffloc = S.buffloc[0];
+                GcNoEmit ne;
+                int k = 0;
+                const double yspc = __ddiv_rn(1.0, spc);
+                const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
+                for (int e = 0; e < want; e++) {
+                    if (!(have_data && bufflocnow > buffloc)) { if (lane == 0) S.starved = 1; break; }
+                    // (dlen - remcode) / (codefreq / f_sf), ref src/sdrtrk.c:31-32: correctly rounded through the reciprocal
+                    // (gc_div_y) where that is safe, as the batch planner divides
+                    const double num = __dsub_rn(dlen, remcode);
+                    const double q = fastdiv ? gc_div_y(num, spc, yspc) : __ddiv_rn(num, spc);
+                    const int n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
+                    const bool valid = n > 0 && n <= max_n && shape_ok;
+                    if (lane == 0) {
+                        S.n[e] = n;
+                        S.valid[e] = valid ? 1 : 0;
+                        S.remcode[e] = remcode;
+                        S.buffloc[e] = buffloc;
                     }
+                    k = e + 1;
+                    if (want > 1) {
+                        tail_wave_sync();
+                        if (lane == 0) __hip_atomic_store(&S.prog, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (valid) {
+                            double r;
+                            GcCodeClaims cl = S.ccl[e];
+                            const int nt = n + 2 * c.smax;
+                            bool ok = false;
+                            if (inst) {
+                                if (tcls == 0) ok = gc_code_claims_step<IT, 8, false>(S.PC, SC, remcode, nt, cl, &r);
+                                else if (tcls == 1) ok = gc_code_claims_step<IT, GC_CLAIM_TAIL, false>(S.PC, SC, remcode, nt, cl, &r);
+                                else ok = gc_code_claims_step<IT, GC_CLAIM_TAIL2, false>(S.PC, SC, remcode, nt, cl, &r);
+                            }
+                            if (ok) remcode = r;
+                            else if (gc_code_period(S.PC, remcode, nt, fill, &r, ne)) remcode = r;
+                            else remcode = tail_code_slow(ci, remcode, c.clen, c.smax, nt, ne);
+                        }
+                    }
+                    buffloc += (uint64_t)(int64_t)n;
+                    if (lane == 0) { S.remcode[e + 1] = remcode; S.buffloc[e + 1] = buffloc; }
                 }
-                buffloc += (uint64_t)(int64_t)n;
-                if (lane == 0) { S.remcode[e + 1] = remcode; S.buffloc[e + 1] = buffloc; }
-            }
-            tail_wave_sync();
-            if (lane == 0) {
-                S.k = k;
-                __hip_atomic_store(&S.prog, 0x7fffffff, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tail_wave_sync();
+                if (lane == 0) {
+                    S.k = k;
+                    __hip_atomic_store(&S.prog, 0x7fffffff, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+            switch ((want > 1 && S.PC.ok) ? S.PC.itop : 0) {
+            case 7:  code_chain(std::integral_constant<int, 7>{}); break;
+            case 8:  code_chain(std::integral_constant<int, 8>{}); break;
+            case 9:  code_chain(std::integral_constant<int, 9>{}); break;
+            case 10: code_chain(std::integral_constant<int, 10>{}); break;
+            case 11: code_chain(std::integral_constant<int, 11>{}); break;
+            case 12: code_chain(std::integral_constant<int, 12>{}); break;
+            default: code_chain(std::integral_constant<int, 0>{}); break;
             }
         } else if (wave == 0 && want > 1) {
             // the carrier chain, one step behind
