@@ -94,6 +94,18 @@ def channel_set(gc, rank):
     return [gc.Channel(p, dtype=2, f_if=0.0, corrn=corrn, corrd=3, corrp=3) for p in prns]
 
 
+def gpu_clocks():
+    """Clock state of the card as rocm-smi reports it (None when it cannot be read here)."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=10)
+        d = json.loads(r.stdout)
+        k = sorted(d)[0]
+        return {a: b for a, b in d[k].items() if "sclk" in a.lower() or "mclk" in a.lower()}
+    except Exception:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -131,10 +143,16 @@ def cpu_baseline_tracking(orc, data, ringlen, chans, states, seconds_budget=12.0
         list(ex.map(lambda i: run(i, nepoch), range(len(chans))))
     dt = time.time() - t0
     ntap = chans[0].ntap
+    n1 = int(max(50, min(4000, 3.0 / per_call)))         # one core, one channel
+    t1 = time.time()
+    run(0, n1)
+    dt1 = time.time() - t1
     return dict(value=len(chans) * nepoch * ntap / dt, unit="correlations/s", cores=ncores, cpu=cpu_model(), kind="port",
-                sample=f"{len(chans)} channels x {nepoch} epochs x {ntap} taps, oracle literal-NCO correlator "
-                       f"(one thread per channel), {dt:.1f} s wall",
-                x_realtime=nepoch / dt / 1000.0)
+                sample=f"{len(chans)} channels x {nepoch} epochs x {ntap} taps, oracle sdrtracking()/correlator() with the "
+                       f"reference's loops (literal NCOs, dot_23/dot_22 shape; one thread per channel), {dt:.1f} s wall",
+                x_realtime=nepoch / dt / 1000.0,
+                one_core={"value": n1 * ntap / dt1, "unit": "correlations/s", "us_per_correlator_call": dt1 / n1 * 1e6,
+                          "sample": f"1 channel x {n1} epochs on one core, {dt1:.1f} s"})
 
 
 def cpu_baseline_acq(orc, data, ringlen, wrpos, chans, seconds_budget=12.0):
@@ -299,6 +317,32 @@ def main():
     eng.timing(False)
     p_ms, p_n = eng.timing_read("trk_plan")
     s_ms, s_n = eng.timing_read("trk_finish")
+    # ---- what the timed launches computed (outside the timed region): the fetch raises if any planned period lay
+    # outside what the ring held or an NCO table overflowed; then one more launch, channel 0 of which is held to the
+    # CPU oracle period by period (II/QQ and samples per period, bit for bit)
+    integrity = None
+    if world == 1:
+        eng.trk_fetch()
+        integrity = {"ring_and_nco_tables": "no violation over the timed launches (gnsscorr_trk_fetch)"}
+    if world == 1 and not args.no_cpu:              # (the oracle as checker: part of the CPU leg)
+        s0 = eng.trk_get_state()[0]
+        se.step(E, chunk_dev, resident=True)
+        se.wait()
+        II, QQ, ns_ = eng.trk_fetch()
+        import oracle as orc_chk
+        o = orc_chk.make_chan(chans[0].prn, dtype=2, f_if=0.0, corrn=(ntap - 1) // 2, corrd=3, corrp=3)
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = s0["carrfreq"], s0["codefreq"], s0["remcode"], s0["remcarr"]
+        oring = orc_chk.make_ring(host, ringlen, 1 << 62)
+        b, bad = s0["buffloc"], 0
+        ncheck = min(E, 200)
+        for e in range(ncheck):
+            orc_chk.lib().orc_sdrtracking(C.byref(o), C.byref(oring), b)
+            if not (np.array_equal(II[0, e], np.ctypeslib.as_array(o.II)[:ntap]) and
+                    np.array_equal(QQ[0, e], np.ctypeslib.as_array(o.QQ)[:ntap]) and ns_[0, e] == o.currnsamp):
+                bad += 1
+            b += o.currnsamp
+        assert bad == 0, f"bench: {bad} of {ncheck} periods of channel 0 differ from the oracle"
+        integrity["oracle_check"] = f"channel 0, {ncheck} periods of the launch after the timed region: II/QQ/currnsamp bit for bit"
     dt_max = dt
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -319,13 +363,14 @@ def main():
         "metric": METRIC, "value": value, "unit": "correlations/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int8 samples x int8 carrier LUT -> int32 accumulators (exact); NCOs: the reference's fp64 running sums, bit for bit",
-        "data": "synthetic", "x_realtime": x_rt,
+        "data": "synthetic", "x_realtime": x_rt, "gpu_clocks": gpu_clocks() if rank == 0 else None,
         "config": {"workload": "BASELINE configs[2]: 32-SV GPS L1CA tracking, 5-tap E/P/L correlators "
                                "(CORRN=2, CORRD=3), 1 ms coherent, 16.368 Msps int8 IQ, per GPU",
                    "channels_per_gpu": NCH, "epochs_per_launch": E, "launches_per_step": args.inner,
                    "epochs_per_step": E * args.inner, "taps": ntap, "loop": "open (frequencies held per launch); see closed_loop",
                    "if_broadcast": "RCCL broadcast of each step's IF chunk" if world > 1 else "none (1 GPU)"},
         "roofline": roof,
+        "integrity": integrity,
         "kernels_ms_per_launch": {"trk_spec": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_spec")),
                                   "trk_plan": p_ms / max(p_n, 1),
                                   "trk_expand": (lambda a: a[0] / max(a[1], 1))(eng.timing_read("trk_expand")),

@@ -368,6 +368,7 @@ struct RawXCT { RawXC r; float4 ta, tb; };                        // + their 327
 // Lags k < nsamp <= 16384 are wanted, i.e. j < 8192: of a lane's outputs j = o + 1024 q those with
 // q < 8.  Nothing has to wait for the other transform, so the only long-lived registers are the
 // power accumulators.
+#define GC_ACQ_G 4              // channels that share an XCD's forward spectra (acq_corr_kernel)
 template <int NT>
 __global__ __launch_bounds__(NT) void acq_corr_kernel(
     const GcChan *__restrict__ chan, const float2 *__restrict__ tw16k, const float2 *__restrict__ tw32p,
@@ -386,8 +387,16 @@ __global__ __launch_bounds__(NT) void acq_corr_kernel(
     // holds all of them (186 MB).  (Pout: one channel's power array, blocks = its bins.)
     const int tid0 = threadIdx.x;
     const int slot = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int bin = Pout ? qq * 8 + slot : (int)(blockIdx.x % (unsigned)maxfreq);
-    const int ch = Pout ? pout_ch : (int)(blockIdx.x / (unsigned)maxfreq);
+    // Search: blocks b and b + 8 tend to share an XCD (speed only).  XCD `slot` takes the bins slot, slot + 8, ... of
+    // GC_ACQ_G channels at a time: the ~9 spectra X[iteration][bin] it needs per iteration (2.3 MB) and the G code
+    // spectra (1 MB) fit its 4 MB L2, so a spectrum leaves the Infinity Cache once per G channels (and both lag
+    // parities) instead of once per channel and parity; chip-wide the G channels' bins all run side by side, which is
+    // what lets a channel stop at the iteration that acquires it.
+    constexpr int G = GC_ACQ_G;
+    const int bpx = (maxfreq + 7) >> 3;                 // bins per XCD slot
+    const int grp = qq / (bpx * G), rem = qq - grp * (bpx * G);
+    const int bin = Pout ? qq * 8 + slot : (rem / G) * 8 + slot;
+    const int ch = Pout ? pout_ch : grp * G + rem % G;
     if (bin >= maxfreq || (!Pout && ch >= nchg)) return;
     const GcChan &c = chan[ch];
     if (bin >= c.nfreq) return;
@@ -963,16 +972,18 @@ extern "C" int gnsscorr_acq_run(gnsscorr_ctx *ctx, uint64_t wrpos)
     {
         GcTimed t(ctx, "acq_corr");
         static const int nt = getenv("GNSSCORR_ACQ_NT") ? atoi(getenv("GNSSCORR_ACQ_NT")) : 512;
+        // (bins per XCD slot) x (channels, in groups of GC_ACQ_G) x 8 slots
+        const unsigned acq_grid = 8u * (unsigned)((w->maxfreq + 7) / 8) * (unsigned)(GC_ACQ_G * ((ctx->nch + GC_ACQ_G - 1) / GC_ACQ_G));
         if (w->L == 2 * GC_L)
             hipLaunchKernelGGL(acq_corr64_kernel, dim3(8 * ((ctx->nch + 7) / 8) * w->maxfreq), dim3(512), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->tw64p1, w->tw64p3, w->X, w->C, w->iters,
                                w->rows, (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch);
         else if (nt == 1024)
-            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(ctx->nch * w->maxfreq), dim3(1024), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<1024>, dim3(acq_grid), dim3(1024), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch, w->arrive, w->arrive + (size_t)ctx->nch * w->maxintg);
         else
-            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(ctx->nch * w->maxfreq), dim3(512), lds + 256,
+            hipLaunchKernelGGL(acq_corr_kernel<512>, dim3(acq_grid), dim3(512), lds + 256,
                                ctx->stream, ctx->dchan, w->tw16k, w->tw32p, w->X, w->C, w->iters, w->rows,
                                (double *)nullptr, 0, w->maxfreq, w->maxintg, ctx->nch, w->arrive, w->arrive + (size_t)ctx->nch * w->maxintg);
     }

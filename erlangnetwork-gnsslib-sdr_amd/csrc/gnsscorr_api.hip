@@ -892,7 +892,7 @@ extern "C" int gnsscorr_trk_run_loop(gnsscorr_ctx *ctx, int nperiod)
     // synchronised advance by up to loopms periods per step.  The host keeps a bounded number of steps ahead of the
     // device and stops as soon as the device says every channel is done (a pinned word the tail kernel updates).
     const int kmax = ctx->loop_kmax < 1 ? 1 : ctx->loop_kmax;
-    const int BURST = 8, AHEAD = 3;
+    const int BURST = 4, AHEAD = 3;
     hipEvent_t ev[AHEAD] = {nullptr, nullptr, nullptr};
     for (int i = 0; i < AHEAD; i++) GC_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     auto cleanup = [&]() { for (int i = 0; i < AHEAD; i++) if (ev[i]) hipEventDestroy(ev[i]); };

@@ -147,8 +147,9 @@ __device__ __forceinline__ int nav_biti(uint64_t cnt, int rate)
     return (int)(cnt % (uint64_t)rate);
 }
 
-// late_after = 2000 / (ctime * 1000), the threshold of ref src/sdrnav.c:26,30 (the same for every period of a launch)
-__device__ __forceinline__ void nav_step(gnsscorr_loop_t *L, double late_after)
+// late_after = 2000 / (ctime * 1000), the threshold of ref src/sdrnav.c:26,30 (the same for every period of a launch);
+// II0 / oldI0: sdr->trk.II[0] and sdr->trk.oldI[0] as sdrtracking() has left them when it calls sdrnavigation()
+__device__ __forceinline__ void nav_step_io(gnsscorr_loop_t *L, double late_after, double II0, double oldI0)
 {
     GC_FP_STRICT
     const uint64_t cnt = L->cnt;
@@ -158,8 +159,8 @@ __device__ __forceinline__ void nav_step(gnsscorr_loop_t *L, double late_after)
         L->synci = 0;
         L->flagsync = 1;
     }
-    if (!L->flagsync && late) L->flagsync = nav_checksync(L, L->II[0], L->oldI[0]);
-    if (L->flagsync) nav_checkbit(L, L->II[0]);
+    if (!L->flagsync && late) L->flagsync = nav_checksync(L, II0, oldI0);
+    if (L->flagsync) nav_checkbit(L, II0);
 }
 
 // emitters that fill LDS tables (lane-uniform calls from one wavefront).  The table pointers are LDS-typed (address
@@ -357,7 +358,7 @@ __device__ __attribute__((noinline)) double tail_code_slow(double ci, double rem
     return gc_code_rem(cend, smax, ci);
 }
 
-#define GC_TAIL_NW 16           // wavefronts of the tail workgroup
+#define GC_TAIL_NW 8            // wavefronts of the tail workgroup
 struct TailShared {
     gnsscorr_loop_t lp;
     GcTrkState st;                                  // the channel's state while the kernel runs (frequencies: wavefront 0)
@@ -367,7 +368,8 @@ struct TailShared {
     double remcode[GC_STEP_KMAX + 1], remcarr[GC_STEP_KMAX + 1];
     uint64_t buffloc[GC_STEP_KMAX + 1];
     int n[GC_STEP_KMAX], valid[GC_STEP_KMAX], ncar[GC_STEP_KMAX], ncode[GC_STEP_KMAX], bad[GC_STEP_KMAX];
-    int want, k, prog, progc, nexttask, starved;
+    int want, k, prog, progc, nexttask, starved, navdone;
+    int nflagsync[GC_STEP_KMAX], nswloop[GC_STEP_KMAX], nbit[GC_STEP_KMAX];     // sdrnavigation()'s verdict per closing period
     int psum[GC_STEP_KMAX][2 * GNSSCORR_MAXTAPS];   // the closing interval's correlator sums: [period][tap | ntap + tap]
     GcCodeClaims ccl[GC_STEP_KMAX];                 // the periods' claims (gnsscorr_nco.h: period steps on claims), discovered
     GcCarClaims kcl[GC_STEP_KMAX];                  // side by side, one lane per period, then evaluated and checked by the chain
@@ -417,9 +419,10 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
         for (int i = tid; i < (int)(sizeof(gnsscorr_loop_t) / 8); i += 64 * GC_TAIL_NW) dst[i] = src[i];
     }
     GcStepMeta m = meta[ch];
-    if (tid == 0) S.st = state[ch];
+    if (tid == 0) { S.st = state[ch]; S.navdone = 0; }
     __syncthreads();
     gnsscorr_loop_t *lp = &S.lp;
+    const double II0_before = S.lp.II[0];               // trk.II[0] of the last period closed (wavefront 0 overwrites it below)
     const bool was_finished = m.finished != 0;
     GC_TSTAMP(0);       // state in
 
@@ -435,9 +438,25 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
     }
     __syncthreads();
     GC_TSTAMP(1);       // sums
+    // sdrnavigation()'s bit synchronisation / bit decision for every period of the interval (ref src/sdrnav.c:18-36): it
+    // only looks at the prompt sums trk.II[0] / trk.oldI[0] and its own state, so wavefront 1 runs it for all periods
+    // while wavefront 0 accumulates; the filters (wavefront 0, below) then find each period's flags in LDS.
+    if (wave == 1 && lane == 0 && m.k > 0) {
+        const double late_after = __ddiv_rn(2000.0, __dmul_rn(lp->ctime, 1000.0));
+        double prevII0 = II0_before;                    // trk.II[0] of the period before (what memcpy leaves in oldI[0]: ntap >= 3)
+        for (int e = 0; e < m.k; e++) {
+            const double II0 = (double)S.psum[e][ntap] * (1.0 / 32.0);      // trk.II[0] = the correlator's QQ[0] (ref src/sdrtrk.c:42)
+            nav_step_io(lp, late_after, II0, prevII0);
+            S.nflagsync[e] = lp->flagsync;
+            S.nswloop[e] = lp->swloop;
+            S.nbit[e] = (lp->flagsync && lp->swsync) ? lp->bit : 0;
+            lp->cnt = lp->cnt + 1;
+            prevII0 = II0;
+            __hip_atomic_store(&S.navdone, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     if (wave == 0) {
         GcTrkState st = S.st;
-        const double late_after = __ddiv_rn(2000.0, __dmul_rn(lp->ctime, 1000.0));
         for (int e = 0; e < m.k; e++) {
             const int p = m.pbase + e;
             if (lane < ntap) {
@@ -464,14 +483,15 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                 lp->sumQ[lane] = __dadd_rn(lp->sumQ[lane], cI);
             }
             tail_wave_sync();
+            // (this period's nav flags: wavefront 1 is usually ahead)
+            while (__hip_atomic_load(&S.navdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= e) __builtin_amdgcn_s_sleep(1);
             int flag = 0;
             if (lane == 0) {
-                nav_step(lp, late_after);               // (the reference calls it from sdrtracking(), before cumsumcorr: it does not touch the sums)
-                if (!lp->flagsync) {
+                if (!S.nflagsync[e]) {
                     loop_pll(lp, st, 0, lp->ctime);
                     loop_dll(lp, st, 0, lp->ctime);
                     flag = 1;
-                } else if (lp->swloop) {
+                } else if (S.nswloop[e]) {
                     loop_pll(lp, st, 1, (double)lp->loopms / 1000);
                     loop_dll(lp, st, 1, (double)lp->loopms / 1000);
                     flag = 2;
@@ -485,9 +505,8 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                 lg->codeNco = lp->codeNco;
                 lg->freqErr = lp->freqErr;
                 lg->flagloopfilter = flag;
-                lg->flagsync = lp->flagsync;
-                lg->navbit = (lp->flagsync && lp->swsync) ? lp->bit : 0;
-                lp->cnt = lp->cnt + 1;
+                lg->flagsync = S.nflagsync[e];
+                lg->navbit = S.nbit[e];
                 if (flag && e + 1 < m.k) m.early = 1;   // the plan held the frequencies beyond a filter update: must not happen
             }
             flag = __builtin_amdgcn_readfirstlane(flag);

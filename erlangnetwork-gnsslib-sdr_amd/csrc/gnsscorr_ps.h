@@ -6,6 +6,18 @@
 #include <type_traits>
 #include "gnsscorr_internal.h"
 
+#ifdef GC_PS_TRACE      // (tools/debug: shader-clock stamps of sampled correlator workgroups, lane 0 of wave 0)
+#define GC_PS_TRACE_N 2048
+__device__ unsigned long long gc_ps_trace[GC_PS_TRACE_N * 16];
+#define GC_PSTAMP(i) do { if (ptr_) ptr_[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gnsscorr_debug_ps_trace(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_ps_trace), sizeof(unsigned long long) * GC_PS_TRACE_N * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define GC_PSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 // rounds per workgroup of the prefix-sum correlator: a whole period when it fits GC_MAXR rounds
@@ -155,6 +167,11 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
 {
     using L = PsLayout<DTYPE, NIT>;
     constexpr int SPG = L::SPG, LSP = L::LSP, RGRP = L::RGRP, RSAMP = L::RSAMP, LPAD = L::LPAD;
+#ifdef GC_PS_TRACE
+    unsigned long long *ptr_ = nullptr;
+    if (tid == 0 && (blockIdx.x % 15) == 0 && blockIdx.x / 15 < GC_PS_TRACE_N) ptr_ = gc_ps_trace + (blockIdx.x / 15) * 16;
+    GC_PSTAMP(0);
+#endif
     const int ntap = c.ntap;
     const int n = u.n, smax = c.smax, head = u.head, G = u.G;
     const int g0 = seg * RGRP * rpw;
@@ -206,6 +223,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         }
     };
     uint4 vA[NIT], vB[NIT];
+    GC_PSTAMP(1);                                       // unit and channel constants are here
     load_round(0, vA);                                  // in flight while the tables are set up
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
@@ -217,7 +235,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     const int __attribute__((address_space(1))) *edges = (const int __attribute__((address_space(1))) *)(code + 3072);
     const int nedge = c.nedge;
     const int ncar = u.ncar, ncode = u.ncode;
-    if (gs) {           // (the closed-loop kernel's planner writes the tables straight into the LDS image)
+    if (gs) {
         if (tid < ncar) { sk0[tid] = gs->carK0[tid]; scar[tid] = gs->car[tid]; }
         if (tid == ncar) sk0[tid] = 0x7fffffff;
         if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = gs->code[tid - 64];
@@ -241,6 +259,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
     if (tid < 32) wpre[tid] = 0;
     __syncthreads();
+    GC_PSTAMP(2);                                       // tables staged
 
     const bool pm1 = c.pm1 != 0;
     unsigned accI[NTAP], accQ[NTAP], finI = 0, finQ = 0;
@@ -367,7 +386,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                 }
             }
         };
+        if (r == 0) GC_PSTAMP(3);                       // round 0: edge record + piece scan done, samples needed now
         if (!(ablate & 2)) { if (onepiece) run(std::false_type{}); else run(std::true_type{}); }
+        if (r == 0) GC_PSTAMP(4);                       // round 0: mixing done
         // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
         if (q < q1) js = edge_js(q, ed, ew, rhint) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
@@ -383,7 +404,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             }
         }
         lbase[tl] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
+        if (r == 0) GC_PSTAMP(5);                       // round 0: scan + atomics
         __syncthreads();
+        if (r == 0) GC_PSTAMP(6);                       // round 0: barrier
         {
             const int2 tv = *reinterpret_cast<const int2 *>(&wp[8]);
             const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
@@ -429,13 +452,16 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
+        if (r == 0) GC_PSTAMP(7);                       // round 0: look-ups
         if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
+        if (r == 0) GC_PSTAMP(8);                       // round 0: barrier
     };
     for (int r = 0; r < nround; r += 2) {
         round(r, vA, vB);
         if (r + 1 < nround) round(r + 1, vB, vA);
     }
 
+    GC_PSTAMP(9);                                       // all rounds
     // wavefront then workgroup reduction (waves without an edge leave red[] at its initial zero)
     if (busy) {
 #pragma unroll
@@ -459,6 +485,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         pout[tid] = (int)(si + finI);
         pout[ntap_stride + tid] = (int)(sq + finQ);
     }
+    GC_PSTAMP(10);                                      // reduced and stored
 }
 
 

@@ -173,18 +173,34 @@ double orc_rescode_seq(const short *code, int len, double coff, int smax,
 /* tracking correlator                                                       */
 /* ------------------------------------------------------------------------- */
 
-/* ref src/sdrcmn.c:287-354 (dot_22 / dot_23): double accumulators of
- * short*short products; one generic routine covers both tap counts. */
-static void dot_taps(const short *a1, const short *a2, const short *const *b,
-                     int nb, int n, double *d1, double *d2)
+/* dot_23 / dot_22, ref src/sdrcmn.c:307-354: two input rows against three / two replica rows in one pass, double
+ * accumulators of short*short products, the accumulations written out one by one as in the reference (so that the
+ * CPU baseline runs the loops the reference's code runs). */
+static void orc_dot_23(const short *a1, const short *a2, const short *b1, const short *b2, const short *b3, int n,
+                       double *d1, double *d2)
 {
-    int i, k;
-    for (i = 0; i < nb; i++) d1[i] = d2[i] = 0.0;
-    for (k = 0; k < n; k++)
-        for (i = 0; i < nb; i++) {
-            d1[i] += a1[k] * b[i][k];
-            d2[i] += a2[k] * b[i][k];
-        }
+    const short *p1 = a1, *p2 = a2, *q1 = b1, *q2 = b2, *q3 = b3;
+    d1[0] = d1[1] = d1[2] = d2[0] = d2[1] = d2[2] = 0.0;
+    for (; p1 < a1 + n; p1++, p2++, q1++, q2++, q3++) {
+        d1[0] += (*p1) * (*q1);
+        d1[1] += (*p1) * (*q2);
+        d1[2] += (*p1) * (*q3);
+        d2[0] += (*p2) * (*q1);
+        d2[1] += (*p2) * (*q2);
+        d2[2] += (*p2) * (*q3);
+    }
+}
+
+static void orc_dot_22(const short *a1, const short *a2, const short *b1, const short *b2, int n, double *d1, double *d2)
+{
+    const short *p1 = a1, *p2 = a2, *q1 = b1, *q2 = b2;
+    d1[0] = d1[1] = d2[0] = d2[1] = 0.0;
+    for (; p1 < a1 + n; p1++, p2++, q1++, q2++) {
+        d1[0] += (*p1) * (*q1);
+        d1[1] += (*p1) * (*q2);
+        d2[0] += (*p2) * (*q1);
+        d2[1] += (*p2) * (*q2);
+    }
 }
 
 /* ref src/sdrcmn.c:687-722 */
@@ -197,19 +213,16 @@ void orc_correlator(const signed char *data, int dtype, double ti, int n,
     short *dI = (short *)malloc(sizeof(short) * (size_t)(n + 64));
     short *dQ = (short *)malloc(sizeof(short) * (size_t)(n + 64));
     short *ce = (short *)malloc(sizeof(short) * (size_t)(n + 2 * smax + 1));
-    const short *code, *b[3];
+    const short *code;
     if (!dI || !dQ || !ce) { free(dI); free(dQ); free(ce); return; }
     code = ce + smax;
 
     *remp = orc_mixcarr_seq(data, dtype, ti, n, freq, phi0, dI, dQ);
     *remc = orc_rescode_seq(codein, coden, coff, smax, ti * crate, n, ce);
     /* P, E1, L1 then (Ei, Li) pairs: ref :712-715 */
-    b[0] = code; b[1] = code - s[0]; b[2] = code + s[0];
-    dot_taps(dI, dQ, b, 3, n, II, QQ);
-    for (i = 1; i < ns; i++) {
-        b[0] = code - s[i]; b[1] = code + s[i];
-        dot_taps(dI, dQ, b, 2, n, II + 1 + i * 2, QQ + 1 + i * 2);
-    }
+    orc_dot_23(dI, dQ, code, code - s[0], code + s[0], n, II, QQ);
+    for (i = 1; i < ns; i++)
+        orc_dot_22(dI, dQ, code - s[i], code + s[i], n, II + 1 + i * 2, QQ + 1 + i * 2);
     for (i = 0; i < 1 + 2 * ns; i++) {
         II[i] *= ORC_CSCALE;
         QQ[i] *= ORC_CSCALE;

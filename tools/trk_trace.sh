@@ -1,17 +1,35 @@
 #!/bin/bash
-# Phase time stamps of sampled trk_corr workgroups (library built with -DGC_TRK_TRACE): lane 0 of
-# wave 0 and of wave 3, round 1 of the period.
-export GNSSCORR_LIB=$PWD/tools/variants/lib_trace.so GNSSCORR_TRACE_OUT=$PWD/gpurun_out/trk_trace.npy
+# Shader-clock stamps of sampled trk_corr_ps workgroups (library built with -DGC_PS_TRACE: gnsscorr_ps.h), lane 0 of
+# wave 0: where a (channel, period) unit spends its lifetime.
+export GNSSCORR_LIB=$PWD/tools/variants/lib_pstrace.so
 mkdir -p gpurun_out
-python bench.py --steps 1 --warmup 1 --no-cpu --no-acq > gpurun_out/trk_trace.json 2> gpurun_out/trk_trace.err || { tail -5 gpurun_out/trk_trace.err; exit 1; }
 python - <<'PY'
-import numpy as np, json
-t=np.load("gpurun_out/trk_trace.npy").astype(np.int64)
-for wv,name in ((0,"wave 0"),(1,"wave 3")):
-    x=t[wv::2]; x=x[(x[:,7]>0)&(x[:,0]>0)&(x[:,2]>0)]
-    print(name,"sampled",len(x),"WG lifetime cycles mean %.0f"%(x[:,7]-x[:,0]).mean(), "wall us %.2f"%((x[:,9]-x[:,8]).mean()/100))
-    seq=[("prologue (start->round0)",0,10),("round0",10,2),("A (mix+scan+atomics)",2,3),("barrier1",3,4),("lbase+barrier2",4,5),("B look-ups",5,6),("barrier3",6,1),("rounds 2..",1,11),("reduce+store",11,7)]
-    for n,a,b in seq:
-        d=x[:,b]-x[:,a]; print("  %-24s mean %7.0f median %7.0f p90 %7.0f"%(n,d.mean(),np.median(d),np.percentile(d,90)))
-print(json.load(open("gpurun_out/trk_trace.json"))["kernels_ms_per_step"])
+import sys, os, ctypes as C, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import gnsscorr_loader
+gc = gnsscorr_loader.load()
+NS, E = 16368, 1000
+rng = np.random.default_rng(3)
+data = rng.integers(-60, 61, size=((E + 4) * NS, 2), dtype=np.int8)
+eng = gc.Engine(0)
+eng.ring_create(1, 2, data.shape[0]); eng.ring_push_raw(1, data, data.shape[0])
+chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, 33)]
+eng.set_channels(chans)
+st0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)), remcode=float(rng.uniform(0.01, 0.99)),
+            remcarr=float(rng.uniform(0, 6.2)), buffloc=int(rng.integers(0, NS))) for c in chans]
+for rep in range(3):
+    eng.trk_set_state(st0)
+    eng.trk_run(E)
+    eng.sync()
+t = np.zeros(2048 * 16, dtype=np.uint64)
+gc.lib().gnsscorr_debug_ps_trace(C.c_void_p(t.ctypes.data))
+x = t.reshape(2048, 16).astype(np.int64)
+x = x[(x[:, 10] > x[:, 0]) & (x[:, 0] > 0)]
+names = ["unit + channel constants", "tables staged (+barrier)", "round 0: records, piece scan", "round 0: mixing (waits for the samples)",
+         "round 0: scan + atomics", "round 0: barrier", "round 0: look-ups", "round 0: barrier", "rounds 1..3", "reduce + store"]
+print("sampled workgroups", len(x), " lifetime clocks mean %.0f median %.0f" % ((x[:, 10] - x[:, 0]).mean(), np.median(x[:, 10] - x[:, 0])))
+for i, n in enumerate(names):
+    d = x[:, i + 1] - x[:, i]
+    print("  %-42s mean %7.0f median %7.0f p90 %7.0f" % (n, d.mean(), np.median(d), np.percentile(d, 90)))
 PY
