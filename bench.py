@@ -237,7 +237,8 @@ def main():
         host, sats = None, None
 
     stream = torch.cuda.current_stream()
-    eng = gc.Engine(dev_index, stream=stream.cuda_stream)
+    # (BENCH_OWN_STREAM: the engine on a stream of its own -- ShardedEngine orders it against torch's with events)
+    eng = gc.Engine(dev_index) if os.environ.get("BENCH_OWN_STREAM") else gc.Engine(dev_index, stream=stream.cuda_stream)
     ring_t = torch.zeros(ringlen * 2, dtype=torch.int8, device=dev)         # the HBM ring of this rank
     chans = channel_set(gc, rank)
     se = mg.ShardedEngine(eng, ring_t, chans, chunk, 2, dist=dist, rank=rank, world=world, strong=False)
@@ -300,12 +301,16 @@ def main():
         ps = np.zeros(8, dtype=np.uint64)
         gc.lib().gnsscorr_debug_plan_stats(ctypes.c_void_p(ps.ctypes.data), 1)
         log("planner paths [code spec, cert, walk | carrier spec, cert, walk]:", ps[:6].tolist())
-        if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):
-            pp = np.zeros(16, dtype=np.uint64)
+        if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):          # (library built with -DGC_PLAN_PROF)
+            pp = np.zeros(64 * 16, dtype=np.uint64)
             gc.lib().gnsscorr_debug_plan_prof(ctypes.c_void_p(pp.ctypes.data))
-            nper = E * args.inner * (args.steps + args.warmup) + E
-            log("planner clocks/period, channel 0: code [rows+n, step, rest, block] carrier [wait, rows, -, step]:",
-                [round(float(v) / nper, 1) for v in pp[:8]])
+            pp = pp.reshape(64, 8, 2)[:NCH].astype(np.float64)
+            nl = args.inner * (args.steps + args.warmup) + 1
+            tot = pp[:, 0, 1] / nl
+            log("planner clocks per launch and channel (total): min %.0f median %.0f max %.0f (channel %d)" % (tot.min(), np.median(tot), tot.max(), int(tot.argmax())))
+            for chx in (int(tot.argmin()), int(tot.argmax())):
+                log("  channel %d: work clocks per launch by wavefront [code chain, carrier chain, code checkers x3, carrier checkers x3]:" % chx,
+                    [int(v) for v in pp[chx, :, 0] / nl], "carrfreq %.1f" % states0[chx]["carrfreq"])
     k_ms, k_n = eng.timing_read("trk_corr")
     # per-kernel times of the whole step: two more steps, every kernel bracketed by events (not part of `value`)
     eng.timing_reset()

@@ -1,6 +1,6 @@
 // gnsscorr_plan.hip -- the tracking planner: the NCO chain of sdrtracking() from period to period
 // (ref src/sdrtrk.c:31-43), bit for bit.  Discovery pass (trk_spec_kernel), the evaluating chain
-// (trk_plan2_kernel) and the chain that certifies its own crossings (trk_plan_kernel); DESIGN.md 3.1,
+// (trk_plan3_kernel) and the chain that certifies its own crossings (trk_plan_kernel); DESIGN.md 3.1,
 // gnsscorr_nco.h.  Compiled on its own: the step instances make it the longest translation unit.
 #include <cstdlib>
 #include <cstddef>
@@ -22,7 +22,7 @@ namespace {
 // Discovery pass of the batch planner: one lane per (channel, period).  From the batch's start state and the
 // closed-form period starts (gc_spec_start) it runs the period steps in their discovering form
 // (gnsscorr_nco.h: "period steps on claims") and keeps the structure they find: GC_CLAIM_ROW ints per NCO
-// and period.  What is sequential in a batch -- trk_plan2_kernel -- then only evaluates and checks.
+// and period.  What is sequential in a batch -- trk_plan3_kernel -- then only evaluates (and checks beside it).
 __global__ __launch_bounds__(64) void trk_spec_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
                                                        int *__restrict__ claims_code, int *__restrict__ claims_car,
                                                        int nch, int nepoch, int e_off)
@@ -208,29 +208,34 @@ __global__ __launch_bounds__(128) void trk_plan_kernel(const GcChan *__restrict_
     trk_plan_body(chan, state_in, state_out, plan, nch, nepoch);
 }
 
-// ---- the batch planner's chain: evaluate and check (gnsscorr_nco.h: "period steps on claims") ----
-// Same two wavefronts per channel.  Each stages the claims of GC_PLAN_BLK periods at a time in LDS (the next
-// block's rows are in flight while this one is evaluated), keeps the periods' results in its lanes (lane l:
-// period l of the block) and writes them out once per block; the carrier wavefront starts a block when the
-// code wavefront has finished it, so the period lengths it needs are all there.
-#define GC_PLAN_BLK 32
-struct Plan2Shared {
+// ---- the batch planner's chain (gnsscorr_nco.h: "period steps on claims") ----
+// What the step on claims computes falls in two parts of very different cost: the VALUES -- the period's start
+// carried through ~60 dependent fp64 operations to the next period's start: 0.28 us (code) / 0.39 us (carrier) per
+// period on a lone wavefront -- and the CHECKS that make the claims the definitions they are: another 0.4 us of
+// compares and mask arithmetic in the same instruction stream (tools/ubench/claims_chain.hip).  Only the values are
+// sequential.  So one wavefront per NCO chains the values (the same step function, its verdict unused: the compiler
+// drops the checks) and publishes every period's start in LDS; three more per NCO take the periods in turn, run the
+// complete step from the published start with the same claims, and report the first period whose claims do not hold
+// or whose value differs.  The batch goes by in blocks of GC_P3_BLK periods: at the end of a block the workgroup
+// meets; if a period failed, the block is redone from that period on -- its own step by the certified path (exact
+// whatever the claims say), the rest on claims again -- until no check fails (a few periods in ten thousand fail).
+// Every value that leaves the kernel has therefore been produced by a step that passed its checks, or by the
+// certified step: the same guarantee as the chain that evaluated and checked in one wavefront (round 2: 0.94 us per
+// period; this: ~0.45).
+#define GC_P3_BLK 64            // periods per block
+#define GC_P3_NW 8              // wavefronts: code chain, carrier chain, 3 code checkers, 3 carrier checkers
+#define GC_P3_NCHK 3
+#define GC_P3_NONE 0x7fffffff
+struct Plan3Shared {
+    int rows[3][2][GC_P3_BLK * GC_CLAIM_ROW];      // [block mod 3][code | carrier][period of the block][GC_CLAIM_ROW]
+    double vcode[2][GC_P3_BLK + 1];                 // [block parity] remcode at the start of each period of the block (+ the next block's first)
+    unsigned long long vbuff[2][GC_P3_BLK + 1];     // buffloc likewise
+    int vn[2][GC_P3_BLK];                           // samples per period
+    double vcar[GC_P3_BLK + 1];                     // remcarr at the start of each period of the carrier's block
+    int prog_code, prog_car, fail_code, fail_car;
     int Ks2[2][GC_NB + 2];
-    int nsh[GC_PLAN_MAXE];
-    int prog;
-    int pad[3];
-    int rows[2][2][(GC_PLAN_BLK + 1) * GC_CLAIM_ROW];     // (+1 row: the row after a block's last is read, never used)
 };
-
-#ifdef GC_PLAN_PROF
-__device__ unsigned long long gc_plan_prof[16];
-#define GC_PP(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); pp[i] += t1_ - pp_t; pp_t = t1_; } while (0)
-#else
-#define GC_PP(i) do { } while (0)
-#endif
-// (file scope: the two wave functions below are called, not inlined -- each instance of the code step gets its
-// own register allocation -- and reach the workgroup's LDS by name)
-__shared__ __attribute__((aligned(16))) Plan2Shared g_plan2;
+__shared__ __attribute__((aligned(16))) Plan3Shared g_plan3;
 
 // (arguments of a called function arrive in vector registers: what is the same in every lane is said so)
 __device__ __forceinline__ int plan2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -257,35 +262,30 @@ __device__ __forceinline__ void plan2_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// claims rows as the kernels move them (five 16-byte quads) -> fields
-__device__ __forceinline__ GcCodeClaims plan2_code_row(const int4 (&v)[GC_CLAIM_ROW / 4])
+// a claims row in LDS -> fields
+__device__ __forceinline__ GcCodeClaims plan3_code_row(const int *row)
 {
+    const int4 *r = reinterpret_cast<const int4 *>(row);
+    const int4 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
     GcCodeClaims c;
-    c.tag = v[0].x; c.i0 = v[0].y; c.q = v[0].z; c.nl = v[0].w;
-    c.jsum = v[1].x; c.dm[0] = v[1].y; c.dm[1] = v[1].z; c.dm[2] = v[1].w;
-    c.dm[3] = v[2].x; c.dm[4] = v[2].y; c.dm[5] = v[2].z; c.dm[6] = v[2].w;
-    c.dm[7] = v[3].x; c.dm[8] = v[3].y; c.dm[9] = v[3].z; c.dm[10] = v[3].w;
-    c.dm[11] = v[4].x; c.dm[12] = v[4].y; c.pad[0] = 0; c.pad[1] = 0;
+    c.tag = v0.x; c.i0 = v0.y; c.q = v0.z; c.nl = v0.w;
+    c.jsum = v1.x; c.dm[0] = v1.y; c.dm[1] = v1.z; c.dm[2] = v1.w;
+    c.dm[3] = v2.x; c.dm[4] = v2.y; c.dm[5] = v2.z; c.dm[6] = v2.w;
+    c.dm[7] = v3.x; c.dm[8] = v3.y; c.dm[9] = v3.z; c.dm[10] = v3.w;
+    c.dm[11] = v4.x; c.dm[12] = v4.y; c.pad[0] = 0; c.pad[1] = 0;
     return c;
 }
-__device__ __forceinline__ GcCarClaims plan2_car_row(const int4 (&v)[GC_CLAIM_ROW / 4])
+__device__ __forceinline__ GcCarClaims plan3_car_row(const int *row)
 {
+    const int4 *r = reinterpret_cast<const int4 *>(row);
+    const int4 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
     GcCarClaims c;
-    c.tag = v[0].x; c.nl = v[0].y; c.i0 = v[0].z; c.nseg = v[0].w;
-    c.kprem = v[1].x; c.dm[0] = v[1].y; c.dm[1] = v[1].z; c.dm[2] = v[1].w;
-    c.dm[3] = v[2].x; c.dm[4] = v[2].y; c.dm[5] = v[2].z; c.dm[6] = v[2].w;
-    c.dm[7] = v[3].x; c.dm[8] = v[3].y; c.dm[9] = v[3].z; c.dm[10] = v[3].w;
-    c.dm[11] = v[4].x; c.dm[12] = v[4].y; c.pad[0] = 0; c.pad[1] = 0;
+    c.tag = v0.x; c.nl = v0.y; c.i0 = v0.z; c.nseg = v0.w;
+    c.kprem = v1.x; c.dm[0] = v1.y; c.dm[1] = v1.z; c.dm[2] = v1.w;
+    c.dm[3] = v2.x; c.dm[4] = v2.y; c.dm[5] = v2.z; c.dm[6] = v2.w;
+    c.dm[7] = v3.x; c.dm[8] = v3.y; c.dm[9] = v3.z; c.dm[10] = v3.w;
+    c.dm[11] = v4.x; c.dm[12] = v4.y; c.pad[0] = 0; c.pad[1] = 0;
     return c;
-}
-// "these claims are here": the LDS reads that brought them were issued a period ago.  Said before the next
-// period's reads are issued, it keeps the compiler from waiting for THOSE at the first use of these.
-template <class T>
-__device__ __forceinline__ void plan2_touch(T &c)
-{
-    int *p = reinterpret_cast<int *>(&c);
-#pragma unroll
-    for (int i = 0; i < GC_CLAIM_ROW; i++) asm volatile("" : "+v"(p[i]));
 }
 static_assert(sizeof(GcCodeClaims) == GC_CLAIM_ROW * 4 && sizeof(GcCarClaims) == GC_CLAIM_ROW * 4, "claims rows are GC_CLAIM_ROW ints");
 static_assert(offsetof(GcCodeClaims, dm) == 20 && offsetof(GcCarClaims, dm) == 20, "claims layout");
@@ -306,7 +306,7 @@ __device__ __attribute__((noinline)) int plan2_code_slow(double ci_, int clen_, 
     const double smaxci = __dmul_rn((double)smax, ci);
     const double c0 = gc_code_start_fast(remcode, smaxci, clen);
     double cend;
-    if (!plan_code_dev(PC.f, c0, clen, n + 2 * smax, g_plan2.Ks2[0], lane, &cend))
+    if (!plan_code_dev(PC.f, c0, clen, n + 2 * smax, g_plan3.Ks2[0], lane, &cend))
         cend = gc_fast_code_walk(PC.f, c0, clen, n + 2 * smax, ne);
     *out = __dsub_rn(cend, smaxci);
     return 2;
@@ -324,314 +324,339 @@ __device__ __attribute__((noinline)) int plan2_car_slow(double ps_, double remca
     if (gc_carrier_period(PK, remcarr, n, fill, &rp)) { *out = rp; return 1; }
     const double phis = gc_div_y(__dmul_rn(remcarr, GC_NCO_CDIV), GC_NCO_DPI, __ddiv_rn(1.0, GC_NCO_DPI));     // ref src/sdrcmn.c:649
     double xn;
-    if (!plan_carrier_dev(PK.f, phis, n, g_plan2.Ks2[1], lane, &xn)) xn = gc_fast_carrier_walk(PK.f, phis, n, ne);
+    if (!plan_carrier_dev(PK.f, phis, n, g_plan3.Ks2[1], lane, &xn)) xn = gc_fast_carrier_walk(PK.f, phis, n, ne);
     *out = gc_fast_prem(PK.fprem, xn);
     return 2;
 }
 
-template <int ITOP, int TMAX>
-__device__ __attribute__((noinline)) void plan2_code_wave(const GcChan &c_, GcTrkState s_, GcTrkState *__restrict__ state_out_,
-                                                GcTrkPlan *__restrict__ out_, int nepoch_, const int4 *__restrict__ src_, int lane, int dbg_)
-{
-    // the channel constants the loop needs, as values (the reference points into the caller's frame)
-    struct { double ti, f_sf; int clen, smax; } c;
-    c.ti = plan2_uni(c_.ti);
-    c.f_sf = plan2_uni(c_.f_sf);
-    c.clen = plan2_uni(c_.clen);
-    c.smax = plan2_uni(c_.smax);
+__device__ __forceinline__ int plan3_load(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void plan3_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+#ifdef GC_PLAN_PROF     // (tools/debug: per channel and wavefront, clocks inside the role's work and inside the whole protocol)
+__device__ unsigned long long gc_plan_prof[64 * 16];
+#endif
+struct Plan3Job {               // what every wavefront of the workgroup knows about the batch
+    const int4 *claims_code, *claims_car;           // the channel's rows
+    GcTrkPlan *out;
     GcTrkState s;
-    s.carrfreq = plan2_uni(s_.carrfreq);
-    s.codefreq = plan2_uni(s_.codefreq);
-    s.remcode = plan2_uni(s_.remcode);
-    s.remcarr = plan2_uni(s_.remcarr);
-    s.buffloc = gc_d2u(plan2_uni(gc_u2d(s_.buffloc)));
-    GcTrkState *__restrict__ state_out = plan2_uni(state_out_);
-    GcTrkPlan *__restrict__ out = plan2_uni(out_);
-    const int4 *__restrict__ src = plan2_uni(src_);
-    const int nepoch = plan2_uni(nepoch_), dbg = plan2_uni(dbg_);
-    const double ci = __dmul_rn(c.ti, s.codefreq);
-    const double spc = __ddiv_rn(s.codefreq, c.f_sf);
-    const double dlen = (double)c.clen;
-    const bool code_ok = ci > 0.0 && ci < dlen;
+    int nepoch, nblk, tid;
+    bool code_ok;
+};
+
+// The block protocol, run by every wavefront of the workgroup in step (the barriers pair up whatever the role).
+// Super-round r: the code roles work on block r, the carrier roles on block r - 1 (whose period lengths are final by
+// then: the carrier never waits for the code chain inside a block).  Within a super-round each NCO repeats its block
+// from the first period whose check failed until none fails.
+// work_code(block, start, nb, redo), work_car(block, start, nb, redo): the calling wavefront's share (empty for the other NCO's roles).
+template <class WorkCode, class WorkCar>
+__device__ __forceinline__ void plan3_protocol(const Plan3Job &J, WorkCode work_code, WorkCar work_car)
+{
+    constexpr int RW4 = GC_CLAIM_ROW / 4;
+    const int tid = J.tid;
+    auto nb_of = [&](int b) { const int left = J.nepoch - b * GC_P3_BLK; return left < GC_P3_BLK ? left : GC_P3_BLK; };
+    auto stage = [&](int b) {   // the claims of block b: [code | carrier][period][row]
+        const int e0 = b * GC_P3_BLK, nb = nb_of(b);
+        for (int x = tid; x < 2 * nb * RW4; x += 64 * GC_P3_NW) {
+            const int which = x / (nb * RW4), r = x - which * nb * RW4;
+            reinterpret_cast<int4 *>(g_plan3.rows[b % 3][which])[r] = (which ? J.claims_car : J.claims_code)[(size_t)e0 * RW4 + r];
+        }
+    };
+#ifdef GC_PLAN_PROF
+    unsigned long long pw_ = 0, pt0_ = __builtin_readcyclecounter();
+#endif
+    if (tid == 0) {
+        g_plan3.vcode[0][0] = J.s.remcode;
+        g_plan3.vbuff[0][0] = J.s.buffloc;
+        g_plan3.vcar[0] = J.s.remcarr;
+    }
+    stage(0);
+    __syncthreads();
+    for (int r = 0; r <= J.nblk; r++) {
+        if (r + 1 < J.nblk) stage(r + 1);               // (lands while this super-round runs; its closing barrier orders it)
+        int cstart = 0, credo = 0, kstart = 0, kredo = 0;
+        bool cdone = r >= J.nblk || !J.code_ok, kdone = r < 1 || !J.code_ok;
+        const int cnb = r < J.nblk ? nb_of(r) : 0, knb = r >= 1 ? nb_of(r - 1) : 0;
+        while (!(cdone && kdone)) {
+            if (tid == 0) {
+                if (!cdone) { g_plan3.prog_code = cstart; g_plan3.fail_code = GC_P3_NONE; }
+                if (!kdone) { g_plan3.prog_car = kstart; g_plan3.fail_car = GC_P3_NONE; }
+            }
+            __syncthreads();
+#ifdef GC_PLAN_PROF
+            const unsigned long long pa_ = __builtin_readcyclecounter();
+#endif
+            if (!cdone) work_code(r, cstart, cnb, credo);
+            if (!kdone) work_car(r - 1, kstart, knb, kredo);
+#ifdef GC_PLAN_PROF
+            pw_ += __builtin_readcyclecounter() - pa_;
+#endif
+            __syncthreads();
+            if (!cdone) {
+                const int f = g_plan3.fail_code;
+                if (f == GC_P3_NONE) cdone = true; else { cstart = f; credo = 1; }      // (every period before f passed: its start value is exact)
+            }
+            if (!kdone) {
+                const int f = g_plan3.fail_car;
+                if (f == GC_P3_NONE) kdone = true; else { kstart = f; kredo = 1; }
+            }
+            __syncthreads();                            // (the fail words are reset at the top)
+        }
+        // block r - 1 is complete: its plan entries, one lane per period
+        if (r >= 1) {
+            const int bp = (r - 1) & 1, e0 = (r - 1) * GC_P3_BLK;
+            if (tid < knb) {
+                GcTrkPlan &o = J.out[e0 + tid];
+                if (J.code_ok) {
+                    o.buffloc = g_plan3.vbuff[bp][tid];
+                    o.coff = g_plan3.vcode[bp][tid];
+                    o.phi0 = g_plan3.vcar[tid];
+                    o.n = g_plan3.vn[bp][tid];
+                } else {                                // (nothing is stepped: every period starts where the batch did)
+                    o.buffloc = J.s.buffloc;
+                    o.coff = J.s.remcode;
+                    o.phi0 = J.s.remcarr;
+                    o.n = 0;
+                }
+                o.carrfreq = J.s.carrfreq;
+                o.codefreq = J.s.codefreq;
+                o.pad = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && J.code_ok) {
+            if (r < J.nblk) {                           // the next code block starts where this one ended
+                g_plan3.vcode[(r + 1) & 1][0] = g_plan3.vcode[r & 1][cnb];
+                g_plan3.vbuff[(r + 1) & 1][0] = g_plan3.vbuff[r & 1][cnb];
+            }
+            if (r >= 1) g_plan3.vcar[0] = g_plan3.vcar[knb];
+        }
+        __syncthreads();
+    }
+#ifdef GC_PLAN_PROF
+    if ((tid & 63) == 0 && blockIdx.x < 64) {
+        atomicAdd(&gc_plan_prof[blockIdx.x * 16 + (tid >> 6) * 2], pw_);
+        atomicAdd(&gc_plan_prof[blockIdx.x * 16 + (tid >> 6) * 2 + 1], __builtin_readcyclecounter() - pt0_);
+    }
+#endif
+}
+
+// The code NCO's wavefronts.  role 0 chains the values of periods [start, nb) of its block (period `start` by the
+// certified path when `redo`; it stops as soon as a check fails); roles 1..GC_P3_NCHK check periods start + (role - 1),
+// + GC_P3_NCHK, ...  (Out of line, one instance per shape of the code step: its constants sit in registers for the batch.)
+template <int ITOP, int TMAX>
+__device__ __attribute__((noinline)) void plan3_code_wave(int role_, double ci_, double spc_, int clen_, int smax_, const Plan3Job *J_, int lane)
+{
+    const int role = plan2_uni(role_), clen = plan2_uni(clen_), smax = plan2_uni(smax_);
+    const double ci = plan2_uni(ci_), spc = plan2_uni(spc_);
+    const Plan3Job J = *plan2_uni(J_);
+    const double dlen = (double)clen;
     GcCodePlan PC;
-    gc_code_plan_init(PC, ci, c.clen, c.smax);
+    gc_code_plan_init(PC, ci, clen, smax);
     GcCodeStepC<ITOP> SC;
     gc_code_stepc_init(SC, PC);
     const double yspc = __ddiv_rn(1.0, spc);
     const bool fastdiv = spc > 1e-300 && spc < 1e300 && yspc < 1e300;
-    int (*rows)[(GC_PLAN_BLK + 1) * GC_CLAIM_ROW] = g_plan2.rows[0];
-    constexpr int RQ = GC_CLAIM_ROW / 4;
-    // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
-    // until they are used, so the next period's row really is in flight during this period's step)
-    int vzero = 0;
-    asm volatile("" : "+v"(vzero));
     unsigned tally[3] = {0, 0, 0};
-#ifdef GC_PLAN_PROF
-    unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
-#endif
-    const int nblk = (nepoch + GC_PLAN_BLK - 1) / GC_PLAN_BLK;
-    int4 pf[RQ];
-    auto fetch_block = [&](int b) {
-        const int e = b * GC_PLAN_BLK + lane;
-        if (lane < GC_PLAN_BLK && e < nepoch) {
-#pragma unroll
-            for (int q = 0; q < RQ; q++) pf[q] = src[(size_t)e * RQ + q];
-        }
-    };
-    auto store_block = [&](int buf) {
-        if (lane < GC_PLAN_BLK) {
-#pragma unroll
-            for (int q = 0; q < RQ; q++) reinterpret_cast<int4 *>(rows[buf])[lane * RQ + q] = pf[q];
-        }
-        plan2_wave_sync();
-    };
-#pragma unroll
-    for (int q = 0; q < RQ; q++) pf[q] = make_int4(0, 0, 0, 0);
-    fetch_block(0);
-    store_block(0);
-    for (int b = 0; b < nblk; b++) {
-        const int buf = b & 1, e0 = b * GC_PLAN_BLK;
-        const int e1 = e0 + GC_PLAN_BLK < nepoch ? e0 + GC_PLAN_BLK : nepoch;
-        if (b + 1 < nblk) fetch_block(b + 1);
-        uint64_t k_buff = 0;
-        double k_coff = 0.0;
-        int k_n = 0;
-        GcCodeClaims nx;
-        {
-            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + vzero;
-            int4 v[RQ];
-#pragma unroll
-            for (int q = 0; q < RQ; q++) v[q] = r[q];
-            nx = plan2_code_row(v);
-        }
-        for (int e = e0; e < e1; e++) {
-            GC_PP(0);
-            GcCodeClaims cl = nx;
-            plan2_touch(cl);
-            {                                       // the next period's claims, in flight during this one
-                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
-                int4 v[RQ];
-#pragma unroll
-                for (int q = 0; q < RQ; q++) v[q] = r[q];
-                nx = plan2_code_row(v);
+    plan3_protocol(J,
+        [&](int b, int start, int nb, int redo) {
+            const int *rows = g_plan3.rows[b % 3][0];
+            double *vcode = g_plan3.vcode[b & 1];
+            unsigned long long *vbuff = g_plan3.vbuff[b & 1];
+            int *vn = g_plan3.vn[b & 1];
+            if (role == 0) {
+                double remcode = vcode[start];
+                unsigned long long buffloc = vbuff[start];
+                GcCodeClaims nx = plan3_code_row(rows + start * GC_CLAIM_ROW);
+                for (int e = start; e < nb; e++) {
+                    if (((e - start) & 3) == 3 && *(volatile int *)&g_plan3.fail_code != GC_P3_NONE) break;    // a check failed behind us: the block is redone from there
+                    const GcCodeClaims cl = nx;
+                    if (e + 1 < nb) nx = plan3_code_row(rows + (e + 1) * GC_CLAIM_ROW);     // (in flight during this period's step)
+                    const double num = __dsub_rn(dlen, remcode);                    // ref src/sdrtrk.c:31-32
+                    double qn = gc_div_y(num, spc, yspc);
+                    if (__builtin_expect(!fastdiv, 0)) qn = __ddiv_rn(num, spc);
+                    const int n = plan2_uni((qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0);
+                    if (lane == 0) vn[e] = n;
+                    const bool walk = n > 0 && n <= (1 << 24);
+                    if (walk) {
+                        double rc;
+                        if ((redo && e == start) || cl.tag != 1) {  // claims that failed, or none (discovery declined the period): the certified step, exact whatever they say
+                            tally[plan2_code_slow(ci, clen, smax, remcode, n, lane, &rc)]++;
+                        } else {
+                            GcCodeClaims c2 = cl;
+                            (void)gc_code_claims_step<ITOP, TMAX, false>(PC, SC, remcode, n + 2 * smax, c2, &rc);     // the value; the checkers judge
+                        }
+                        remcode = rc;
+                    }
+                    buffloc += (unsigned long long)(long long)n;
+                    // (value, then progress: LDS stores of one lane, executed in order -- a checker that sees the count sees the value)
+                    if (lane == 0) { vcode[e + 1] = remcode; vbuff[e + 1] = buffloc; *(volatile int *)&g_plan3.prog_code = e + 1; }
+                }
+            } else {
+                for (int e = start + role - 1; e < nb; e += GC_P3_NCHK) {
+                    bool stop = false;
+                    while (plan3_load(&g_plan3.prog_code) <= e) {
+                        if (plan3_load(&g_plan3.fail_code) <= e) { stop = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (stop || plan3_load(&g_plan3.fail_code) <= e) break;         // (periods from the failed one on are redone)
+                    if (redo && e == start) continue;   // (computed by the certified path)
+                    const int n = vn[e];
+                    if (!(n > 0 && n <= (1 << 24))) continue;                       // nothing was stepped
+                    const double y0 = vcode[e], y1 = vcode[e + 1];
+                    GcCodeClaims cl = plan3_code_row(rows + e * GC_CLAIM_ROW);
+                    if (cl.tag != 1) continue;          // (no claims: the chain took the certified step)
+                    double rc;
+                    const bool ok = gc_code_claims_step<ITOP, TMAX, false>(PC, SC, y0, n + 2 * smax, cl, &rc);
+                    if (!(ok && rc == y1)) { if (lane == 0) atomicMin(&g_plan3.fail_code, e); }
+                    else tally[0]++;
+                }
             }
-            const double num = __dsub_rn(dlen, s.remcode);                      // ref src/sdrtrk.c:31-32
-            double qn = gc_div_y(num, spc, yspc);
-            if (__builtin_expect(!fastdiv, 0)) qn = __ddiv_rn(num, spc);
-            const int n = plan2_uni((qn > -2147483648.0 && qn < 2147483648.0) ? (int)qn : 0);     // (the same in every lane)
-            const bool mine = lane == e - e0;
-            k_buff = mine ? s.buffloc : k_buff;
-            k_coff = mine ? s.remcode : k_coff;
-            k_n = mine ? n : k_n;
-            g_plan2.nsh[e] = n;                          // (every lane, the same value)
-            GC_PP(1);
-            const bool walk = n > 0 && n <= (1 << 24) && code_ok && !(dbg & 1);
-            double rc, rcf;
-            if (__builtin_expect(walk && gc_code_claims_step<ITOP, TMAX, false>(PC, SC, s.remcode, n + 2 * c.smax, cl, &rcf), 1)) {
-                s.remcode = rcf;
-                tally[0]++;
-            } else if (walk) {
-                tally[plan2_code_slow(ci, c.clen, c.smax, s.remcode, n, lane, &rc)]++;
-                s.remcode = rc;
-            }
-            s.buffloc += (uint64_t)(int64_t)n;
-            GC_PP(2);
-        }
-        if (lane < e1 - e0) {
-            GcTrkPlan &o = out[e0 + lane];
-            o.buffloc = k_buff;
-            o.coff = k_coff;
-            o.carrfreq = s.carrfreq;
-            o.codefreq = s.codefreq;
-            o.n = k_n;
-            o.pad = 0;
-        }
-        __threadfence_block();
-        if (lane == 0) __hip_atomic_store(&g_plan2.prog, e1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (b + 1 < nblk) store_block(buf ^ 1);
-        GC_PP(3);
-    }
-#ifdef GC_PLAN_PROF
-    if (lane == 0 && blockIdx.x == 0)
-        for (int i = 0; i < 4; i++) atomicAdd(&gc_plan_prof[i], pp[i]);
-#endif
+        },
+        [](int, int, int, int) {});
     if (lane == 0) {
-        state_out->carrfreq = s.carrfreq;
-        state_out->codefreq = s.codefreq;
-        state_out->remcode = s.remcode;
-        state_out->buffloc = s.buffloc;
 #pragma unroll
         for (int t = 0; t < 3; t++)
             if (tally[t]) atomicAdd(&gc_plan_stats[t], (unsigned long long)tally[t]);
     }
 }
 
-__device__ __attribute__((noinline)) void plan2_car_wave(const GcChan &c_, GcTrkState s_, GcTrkState *__restrict__ state_out_,
-                                               GcTrkPlan *__restrict__ out_, int nepoch_, const int4 *__restrict__ src_, int lane, int dbg_)
+// The carrier NCO's wavefronts, likewise, one block behind the code's (it needs the period lengths, final by then)
+__device__ __attribute__((noinline)) void plan3_car_wave(int role_, double ps_, int nsamp_, const Plan3Job *J_, int lane)
 {
-    struct { double ti; int nsamp; } c;
-    c.ti = plan2_uni(c_.ti);
-    c.nsamp = plan2_uni(c_.nsamp);
-    GcTrkState s;
-    s.carrfreq = plan2_uni(s_.carrfreq);
-    s.codefreq = plan2_uni(s_.codefreq);
-    s.remcode = plan2_uni(s_.remcode);
-    s.remcarr = plan2_uni(s_.remcarr);
-    s.buffloc = s_.buffloc;
-    GcTrkState *__restrict__ state_out = plan2_uni(state_out_);
-    GcTrkPlan *__restrict__ out = plan2_uni(out_);
-    const int4 *__restrict__ src = plan2_uni(src_);
-    const int nepoch = plan2_uni(nepoch_), dbg = plan2_uni(dbg_);
-    const double ps = gc_carrier_ps(s.carrfreq, c.ti);
+    const int role = plan2_uni(role_), nsamp = plan2_uni(nsamp_);
+    const double ps = plan2_uni(ps_);
+    const Plan3Job J = *plan2_uni(J_);
     GcCarPlan PK;
     gc_car_plan_init(PK, ps, false, false);
     GcCarStepC CK;
-    gc_car_stepc_init(CK, PK, c.nsamp + 16);
-    int (*rows)[(GC_PLAN_BLK + 1) * GC_CLAIM_ROW] = g_plan2.rows[1];
-    constexpr int RQ = GC_CLAIM_ROW / 4;
-    // (a zero the compiler takes for a per-lane value: the claims read through it stay in vector registers
-    // until they are used, so the next period's row really is in flight during this period's step)
-    int vzero = 0;
-    asm volatile("" : "+v"(vzero));
+    gc_car_stepc_init(CK, PK, nsamp + 16);
     unsigned tally[3] = {0, 0, 0};
-#ifdef GC_PLAN_PROF
-    unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter();
-#endif
-    const int nblk = (nepoch + GC_PLAN_BLK - 1) / GC_PLAN_BLK;
-    int4 pf[RQ];
-    auto fetch_block = [&](int b) {
-        const int e = b * GC_PLAN_BLK + lane;
-        if (lane < GC_PLAN_BLK && e < nepoch) {
-#pragma unroll
-            for (int q = 0; q < RQ; q++) pf[q] = src[(size_t)e * RQ + q];
-        }
-    };
-    auto store_block = [&](int buf) {
-        if (lane < GC_PLAN_BLK) {
-#pragma unroll
-            for (int q = 0; q < RQ; q++) reinterpret_cast<int4 *>(rows[buf])[lane * RQ + q] = pf[q];
-        }
-        plan2_wave_sync();
-    };
-#pragma unroll
-    for (int q = 0; q < RQ; q++) pf[q] = make_int4(0, 0, 0, 0);
-    fetch_block(0);
-    store_block(0);
-    for (int b = 0; b < nblk; b++) {
-        const int buf = b & 1, e0 = b * GC_PLAN_BLK;
-        const int e1 = e0 + GC_PLAN_BLK < nepoch ? e0 + GC_PLAN_BLK : nepoch;
-        if (b + 1 < nblk) fetch_block(b + 1);
-        // the code wavefront has finished this block: its period lengths are in nsh[]
-        while (__hip_atomic_load(&g_plan2.prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < e1) __builtin_amdgcn_s_sleep(1);
-        double k_phi = 0.0;
-        GcCarClaims nx;
-        int nn;
-        {
-            const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + vzero;
-            int4 v[RQ];
-#pragma unroll
-            for (int q = 0; q < RQ; q++) v[q] = r[q];
-            nx = plan2_car_row(v);
-            nn = g_plan2.nsh[e0];
-        }
-        GC_PP(4);
-        for (int e = e0; e < e1; e++) {
-            GC_PP(5);
-            GcCarClaims cl = nx;
-            plan2_touch(cl);
-            const int n = plan2_uni(nn);
-            {
-                const int4 *r = reinterpret_cast<const int4 *>(rows[buf]) + (e + 1 - e0) * RQ + vzero;
-                int4 v[RQ];
-#pragma unroll
-                for (int q = 0; q < RQ; q++) v[q] = r[q];
-                nx = plan2_car_row(v);
-                nn = g_plan2.nsh[e + 1 < GC_PLAN_MAXE ? e + 1 : e];
+    plan3_protocol(J,
+        [](int, int, int, int) {},
+        [&](int b, int start, int nb, int redo) {
+            const int *rows = g_plan3.rows[b % 3][1];
+            const int *vn = g_plan3.vn[b & 1];
+            double *vcar = g_plan3.vcar;
+            if (role == 0) {
+                double remcarr = vcar[start];
+                GcCarClaims nx = plan3_car_row(rows + start * GC_CLAIM_ROW);
+                for (int e = start; e < nb; e++) {
+                    if (((e - start) & 3) == 3 && *(volatile int *)&g_plan3.fail_car != GC_P3_NONE) break;
+                    const GcCarClaims cl = nx;
+                    if (e + 1 < nb) nx = plan3_car_row(rows + (e + 1) * GC_CLAIM_ROW);
+                    const int n = plan2_uni(vn[e]);
+                    const bool walk = n > 0 && n <= (1 << 24);
+                    if (walk) {
+                        double rp;
+                        if ((redo && e == start) || cl.tag == 0) {
+                            tally[plan2_car_slow(ps, remcarr, n, lane, &rp)]++;
+                        } else {
+                            GcCarClaims c2 = cl;
+                            (void)gc_carrier_claims_step<false>(PK, CK, remcarr, n, c2, &rp);
+                        }
+                        remcarr = rp;
+                    }
+                    if (lane == 0) { vcar[e + 1] = remcarr; *(volatile int *)&g_plan3.prog_car = e + 1; }
+                }
+            } else {
+                for (int e = start + role - 1; e < nb; e += GC_P3_NCHK) {
+                    bool stop = false;
+                    while (plan3_load(&g_plan3.prog_car) <= e) {
+                        if (plan3_load(&g_plan3.fail_car) <= e) { stop = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (stop || plan3_load(&g_plan3.fail_car) <= e) break;
+                    if (redo && e == start) continue;
+                    const int n = vn[e];
+                    if (!(n > 0 && n <= (1 << 24))) continue;
+                    const double x0 = vcar[e], x1 = vcar[e + 1];
+                    GcCarClaims cl = plan3_car_row(rows + e * GC_CLAIM_ROW);
+                    if (cl.tag == 0) continue;
+                    double rp;
+                    const bool ok = gc_carrier_claims_step<false>(PK, CK, x0, n, cl, &rp);
+                    if (!(ok && rp == x1)) { if (lane == 0) atomicMin(&g_plan3.fail_car, e); }
+                    else tally[0]++;
+                }
             }
-            const bool mine = lane == e - e0;
-            k_phi = mine ? s.remcarr : k_phi;
-            GC_PP(6);
-            const bool walk = n > 0 && n <= (1 << 24) && !(dbg & 2);
-            double rp, rpf;
-            if (__builtin_expect(walk && gc_carrier_claims_step<false>(PK, CK, s.remcarr, n, cl, &rpf), 1)) {
-                s.remcarr = rpf;
-                tally[0]++;
-            } else if (walk) {
-                tally[plan2_car_slow(ps, s.remcarr, n, lane, &rp)]++;
-                s.remcarr = rp;
-            }
-            GC_PP(7);
-        }
-        GC_PP(5);
-        if (lane < e1 - e0) out[e0 + lane].phi0 = k_phi;
-        if (b + 1 < nblk) store_block(buf ^ 1);
-    }
-#ifdef GC_PLAN_PROF
-    if (lane == 0 && blockIdx.x == 0)
-        for (int i = 4; i < 8; i++) atomicAdd(&gc_plan_prof[i], pp[i]);
-#endif
+        });
     if (lane == 0) {
-        state_out->remcarr = s.remcarr;
 #pragma unroll
         for (int t = 0; t < 3; t++)
             if (tally[t]) atomicAdd(&gc_plan_stats[3 + t], (unsigned long long)tally[t]);
     }
 }
 
-__global__ __launch_bounds__(128) void trk_plan2_kernel(const GcChan *__restrict__ chan,
-                                                        const GcTrkState *__restrict__ state_in,
-                                                        GcTrkState *__restrict__ state_out,
-                                                        GcTrkPlan *__restrict__ plan, int nch, int nepoch,
-                                                        const int *__restrict__ claims_code, const int *__restrict__ claims_car, int dbg)
+template <int ITOP>
+__device__ __forceinline__ void plan3_code_dispatch(int tcls, int role, double ci, double spc, int clen, int smax, const Plan3Job *J, int lane)
 {
-    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tcls == 0) plan3_code_wave<ITOP, 8>(role, ci, spc, clen, smax, J, lane);
+    else if (tcls == 1) plan3_code_wave<ITOP, GC_CLAIM_TAIL>(role, ci, spc, clen, smax, J, lane);
+    else plan3_code_wave<ITOP, GC_CLAIM_TAIL2>(role, ci, spc, clen, smax, J, lane);
+}
+
+__global__ __launch_bounds__(64 * GC_P3_NW) void trk_plan3_kernel(const GcChan *__restrict__ chan, const GcTrkState *__restrict__ state_in,
+                                                                   GcTrkState *__restrict__ state_out, GcTrkPlan *__restrict__ plan,
+                                                                   int nch, int nepoch, const int *__restrict__ claims_code,
+                                                                   const int *__restrict__ claims_car)
+{
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= nch) return;
     const int cls = plan2_class(chan[ch].ti, state_in[ch].codefreq, chan[ch].clen, chan[ch].smax);
     if (cls < 0) {                  // no instance of the batch chain for this channel: the chain that certifies its own crossings
+        if (wave >= 2) return;
         trk_plan_body(chan, state_in, state_out, plan, nch, nepoch);
         return;
     }
-    __builtin_amdgcn_s_setprio(3);
-    if (threadIdx.x == 0) g_plan2.prog = 0;
-    __syncthreads();
     const GcChan c = chan[ch];
     const GcTrkState s = state_in[ch];
-    GcTrkPlan *out = plan + (size_t)ch * nepoch;
-    constexpr int RQ = GC_CLAIM_ROW / 4;
-    if (wave == 1) {
-        plan2_car_wave(c, s, state_out + ch, out, nepoch, reinterpret_cast<const int4 *>(claims_car) + (size_t)ch * nepoch * RQ, lane, dbg);
-        return;
+    const double ci = __dmul_rn(c.ti, s.codefreq), spc = __ddiv_rn(s.codefreq, c.f_sf), ps = gc_carrier_ps(s.carrfreq, c.ti);
+    const int itop = cls / 3 + 7, tcls = cls % 3;
+    constexpr int RW4 = GC_CLAIM_ROW / 4;
+    Plan3Job J;
+    J.claims_code = reinterpret_cast<const int4 *>(claims_code) + (size_t)ch * nepoch * RW4;
+    J.claims_car = reinterpret_cast<const int4 *>(claims_car) + (size_t)ch * nepoch * RW4;
+    J.out = plan + (size_t)ch * nepoch;
+    J.s = s;
+    J.nepoch = nepoch;
+    J.nblk = (nepoch + GC_P3_BLK - 1) / GC_P3_BLK;
+    J.tid = tid;
+    J.code_ok = ci > 0.0 && ci < (double)c.clen;
+    // the value chains issue first on their SIMDs (each shares one with a checker)
+    if (__builtin_amdgcn_readfirstlane(wave) < 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    if (wave == 0 || (wave >= 2 && wave < 2 + GC_P3_NCHK)) {
+        const int role = wave == 0 ? 0 : wave - 1;
+        switch (itop) {
+        case 7:  plan3_code_dispatch<7>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        case 8:  plan3_code_dispatch<8>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        case 9:  plan3_code_dispatch<9>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        case 10: plan3_code_dispatch<10>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        case 11: plan3_code_dispatch<11>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        default: plan3_code_dispatch<12>(tcls, role, ci, spc, c.clen, c.smax, &J, lane); break;
+        }
+    } else {
+        plan3_car_wave(wave == 1 ? 0 : wave - 1 - GC_P3_NCHK, ps, c.nsamp, &J, lane);
     }
-    const int4 *src = reinterpret_cast<const int4 *>(claims_code) + (size_t)ch * nepoch * RQ;
-    switch (cls) {
-    case 0:  plan2_code_wave<7, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 1:  plan2_code_wave<7, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 2:  plan2_code_wave<7, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 3:  plan2_code_wave<8, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 4:  plan2_code_wave<8, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 5:  plan2_code_wave<8, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 6:  plan2_code_wave<9, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 7:  plan2_code_wave<9, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 8:  plan2_code_wave<9, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 9:  plan2_code_wave<10, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 10: plan2_code_wave<10, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 11: plan2_code_wave<10, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 12: plan2_code_wave<11, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 13: plan2_code_wave<11, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 14: plan2_code_wave<11, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 15: plan2_code_wave<12, 8>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    case 16: plan2_code_wave<12, GC_CLAIM_TAIL>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
-    default: plan2_code_wave<12, GC_CLAIM_TAIL2>(c, s, state_out + ch, out, nepoch, src, lane, dbg); break;
+    // the state the batch leaves behind (the protocol carried the ends of the last blocks into the first slots)
+    if (tid == 0) {
+        GcTrkState so;
+        so.carrfreq = s.carrfreq;
+        so.codefreq = s.codefreq;
+        so.remcode = J.code_ok ? g_plan3.vcode[J.nblk & 1][0] : s.remcode;
+        so.buffloc = J.code_ok ? g_plan3.vbuff[J.nblk & 1][0] : s.buffloc;
+        so.remcarr = J.code_ok ? g_plan3.vcar[0] : s.remcarr;
+        state_out[ch] = so;
     }
 }
 
 
 }  // namespace
 
+
 #ifdef GC_PLAN_PROF
 extern "C" int gnsscorr_debug_plan_prof(unsigned long long *dst)
 {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_plan_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_plan_prof), sizeof(unsigned long long) * 64 * 16) != hipSuccess) return -1;
+    return 0;
 }
 #endif
 
@@ -672,9 +697,10 @@ int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *sta
 {
     static const int dbg = getenv("GNSSCORR_PLAN_DBG") ? atoi(getenv("GNSSCORR_PLAN_DBG")) : 0;
     const bool batch = claims && !trk_nospec() && nepoch <= GC_PLAN_MAXE;
+    (void)dbg;
     if (batch)
-        hipLaunchKernelGGL(trk_plan2_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch,
-                           claims, claims + (size_t)nch * nepoch * GC_CLAIM_ROW, dbg);
+        hipLaunchKernelGGL(trk_plan3_kernel, dim3(nch), dim3(64 * GC_P3_NW), 0, st, chan, state_in, state_out, plan, nch, nepoch,
+                           claims, claims + (size_t)nch * nepoch * GC_CLAIM_ROW);
     else
         hipLaunchKernelGGL(trk_plan_kernel, dim3(nch), dim3(128), 0, st, chan, state_in, state_out, plan, nch, nepoch);
     GC_HIP(hipGetLastError());

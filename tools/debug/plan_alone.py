@@ -1,0 +1,23 @@
+"""debug: the planner chain alone on the chip (no correlator beside it): per-launch time of trk_plan from HIP events."""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gnsscorr_loader
+gc = gnsscorr_loader.load()
+NS, E = 16368, 1000
+rng = np.random.default_rng(20240601)
+data = np.random.default_rng(3).integers(-60, 61, size=((E + 4) * NS, 2), dtype=np.int8)
+eng = gc.Engine(0)
+eng.ring_create(1, 2, data.shape[0]); eng.ring_push_raw(1, data, data.shape[0])
+chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, 33)]
+eng.set_channels(chans)
+st0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)), remcode=float(rng.uniform(0.01, 0.99)),
+            remcarr=float(rng.uniform(0, 6.2)), buffloc=int(rng.integers(0, NS))) for c in chans]
+eng.timing(1)
+for rep in range(4):
+    eng.trk_set_state(st0)          # (a touched state: no look-ahead, the plan runs before the correlator, alone)
+    eng.timing_reset()
+    eng.trk_run(E)
+    eng.sync()
+    print({k: round(eng.timing_read(k)[0] / max(eng.timing_read(k)[1], 1), 4) for k in ("trk_spec", "trk_plan", "trk_expand", "trk_edges", "trk_corr")})
