@@ -300,17 +300,19 @@ def main():
         import ctypes
         ps = np.zeros(8, dtype=np.uint64)
         gc.lib().gnsscorr_debug_plan_stats(ctypes.c_void_p(ps.ctypes.data), 1)
-        log("planner paths [code spec, cert, walk | carrier spec, cert, walk]:", ps[:6].tolist())
+        log("planner paths [code claims, cert, walk | carrier claims, cert, walk | failed checks (verify mode), starts outside their bracket]:", ps.tolist())
         if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):          # (library built with -DGC_PLAN_PROF)
             pp = np.zeros(64 * 16, dtype=np.uint64)
             gc.lib().gnsscorr_debug_plan_prof(ctypes.c_void_p(pp.ctypes.data))
-            pp = pp.reshape(64, 8, 2)[:NCH].astype(np.float64)
+            pp = pp.reshape(64, 2, 8)[:NCH].astype(np.float64)
             nl = args.inner * (args.steps + args.warmup) + 1
-            tot = pp[:, 0, 1] / nl
-            log("planner clocks per launch and channel (total): min %.0f median %.0f max %.0f (channel %d)" % (tot.min(), np.median(tot), tot.max(), int(tot.argmax())))
-            for chx in (int(tot.argmin()), int(tot.argmax())):
-                log("  channel %d: work clocks per launch by wavefront [code chain, carrier chain, code checkers x3, carrier checkers x3]:" % chx,
-                    [int(v) for v in pp[chx, :, 0] / nl], "carrfreq %.1f" % states0[chx]["carrfreq"])
+            for name, w in (("code", 0), ("carrier", 1)):
+                tot = pp[:, w, 0] / nl
+                log("planner %s chain, clocks per launch: min %.0f median %.0f max %.0f (channel %d)" % (name, tot.min(), np.median(tot), tot.max(), int(tot.argmax())))
+                for chx in sorted({int(tot.argmin()), int(np.argsort(tot)[len(tot) // 2]), int(tot.argmax())}):
+                    v = pp[chx, w] / nl
+                    log("  channel %d (carrfreq %.1f): loop %.0f  slow path %.0f (%.1f periods)  waiting for rows %.0f  waiting for n %.0f" % (
+                        chx, states0[chx]["carrfreq"], v[0], v[1], v[4], v[2], v[3]))
     k_ms, k_n = eng.timing_read("trk_corr")
     # per-kernel times of the whole step: two more steps, every kernel bracketed by events (not part of `value`)
     eng.timing_reset()

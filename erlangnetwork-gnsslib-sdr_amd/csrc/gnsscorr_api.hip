@@ -601,7 +601,7 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     }
     free_trk_buffers(ctx);
     for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dplan2[i], sizeof(GcTrkPlan) * units));
-    for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dspec2[i], sizeof(int) * 2 * units * GC_CLAIM_ROW));
+    for (int i = 0; i < 2; i++) GC_HIP(hipMalloc((void **)&ctx->dspec2[i], sizeof(int) * gc_trk_spec_ints(units)));
     GC_HIP(hipMalloc((void **)&ctx->detab, sizeof(unsigned short) * units * GC_EDGTAB));
     ctx->spec_ahead_valid = false;
     GC_HIP(hipMalloc((void **)&ctx->dcorrI, sizeof(double) * units * ctx->ntap));
@@ -629,6 +629,19 @@ static int ensure_trk_buffers(gnsscorr_ctx *ctx, int nepoch)
     GC_HIP(hipMemsetAsync(ctx->dring_viol, 0, sizeof(int), ctx->stream));
     ctx->plan_cap = units;
     return GNSSCORR_OK;
+}
+
+// (tools/debug) the claims rows of the batch planned last: code rows, then carrier rows, GC_CLAIM_ROW ints each;
+// returns the number of rows per NCO
+extern "C" int gnsscorr_debug_spec_rows(gnsscorr_ctx *ctx, int *dst, int max_ints)
+{
+    if (!ctx || !ctx->dspec2[ctx->spec_last_buf] || !ctx->spec_last_units) return -1;
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipDeviceSynchronize());
+    const size_t ints = (size_t)2 * ctx->spec_last_units * GC_CLAIM_ROW;
+    if ((size_t)max_ints < ints) return -2;
+    GC_HIP(hipMemcpy(dst, ctx->dspec2[ctx->spec_last_buf], ints * sizeof(int), hipMemcpyDeviceToHost));
+    return ctx->spec_last_units;
 }
 
 extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
@@ -671,6 +684,8 @@ extern "C" int gnsscorr_trk_run(gnsscorr_ctx *ctx, int nepoch)
         }
         ctx->spec_ahead_valid = false;
         ctx->spec_pending = false;
+        ctx->spec_last_buf = buf;
+        ctx->spec_last_units = ctx->nch * nepoch;
         if (ctx->stream4) {
             // the next batch's claims, from the same input state, beside this batch's chain (the other buffer
             // was last read by the chain in front of this one on the planner stream)

@@ -73,6 +73,7 @@ struct gnsscorr_ctx {
     bool spec_pending = false;                     // stream4 has work whose end ev_spec marks
     bool spec_ahead_valid = false;                 // dspec2[spec_ahead_buf] holds claims for the batch that starts at spec_ahead_state
     int spec_ahead_buf = 0, spec_ahead_nepoch = 0;
+    int spec_last_buf = 0, spec_last_units = 0;     // (tools/debug) the claims the last planned batch used
     const void *spec_ahead_state = nullptr;
     int plan_slot = 0;                             // slot the next trk_run consumes
     bool ahead_valid = false;                      // dplan2[plan_slot] already planned (look-ahead)

@@ -131,6 +131,7 @@ struct GcRound {
 };
 
 // kernel launchers (definitions in gnsscorr_trk.hip / gnsscorr_plan.hip / gnsscorr_acq.hip)
+size_t gc_trk_spec_ints(size_t units);
 int gc_launch_trk_spec(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, int nch, int nepoch, int *claims,
                        int e_off);
 int gc_launch_trk_plan(hipStream_t st, const GcChan *chan, const GcTrkState *state_in, GcTrkState *state_out,

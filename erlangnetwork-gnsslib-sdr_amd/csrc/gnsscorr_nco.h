@@ -787,10 +787,11 @@ GC_HD bool gc_plan_code_walk(const GcNcoFast &f, double c, int len, int nt, int 
 // A sum far above its addend (a negative carrier phase is never wrapped, ref src/sdrcmn.c:667: after a
 // fraction of a second it is thousands of LUT steps while the step stays ~0.01) spends the whole period
 // inside one binade: n equal steps d = RN_u(s), if the last one stays below the top of the binade.
-GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn, double *dout = nullptr)
+GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn, double *dout = nullptr, bool *tie_out = nullptr)
 {
     GC_FP_STRICT
     const uint64_t ux = gc_d2u(x), us = gc_d2u(s);
+    if (tie_out) *tie_out = false;
     const int ex = (int)((ux >> 52) & 0x7FF), es = (int)((us >> 52) & 0x7FF);
     if (ex == 0 || ex == 0x7FF || es == 0 || es == 0x7FF || (ux >> 63) != (us >> 63)) return false;
     const int et = es + 1075 - ex;
@@ -799,6 +800,7 @@ GC_HD bool gc_one_binade_walk(double x, double s, int n, double *xn, double *dou
     if (et >= 1023 - 1) {
         const double t = gc_u2d((us & 0x800FFFFFFFFFFFFFull) | ((uint64_t)et << 52));
         b = rint(t);
+        if (tie_out) *tie_out = fabs(t - b) == 0.5;             // (the step then depends on the multiplier's parity)
         if (fabs(t - b) == 0.5 && (ux & 1)) return false;      // tie from an odd multiplier
     }
     const double d = ldexp(b, ex - 1075);
@@ -1283,7 +1285,7 @@ GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc
 // reference's own additions (pre): from an odd multiplier that step rounds to the even neighbour, from an
 // even one it equals the table's step -- either way the rest of the segment starts even, where the table's
 // step holds.
-#define GC_CLAIM_ROW   20           // ints per (channel, period) row of either NCO
+#define GC_CLAIM_ROW   24           // ints per (channel, period) row of either NCO
 #define GC_CLAIM_LIT   5            // code: literal additions after the first wrap, at most (as gc_code_period_body)
 #define GC_CLAIM_TAIL  15           // code: literal additions after the second wrap, at most (tap offsets up to 7 samples: 8 positions)
 #define GC_CLAIM_TAIL2 32           // ... for correlator spacings up to 30 samples (the shipped CORRN=6, CORRD=3: 18)
@@ -1295,14 +1297,16 @@ struct GcCodeClaims {               // GC_CLAIM_ROW ints
     int tag;                        // 1: claims present
     int i0, q, nl, jsum;            // entry binade of the climb, head steps, literal additions, samples before the tail
     int dm[13];                     // equal steps per table binade 0..ITOP (after the tie binade's own addition)
-    int pad[2];
+    int n, pad;                     // bracket form: the period's samples
+    double lo, hi;                  // bracket form: period starts (remcode) the claims were proved for, ends included
 };
 
 struct GcCarClaims {                // GC_CLAIM_ROW ints
     int tag;                        // 1: table walk, 2: one binade far above the table (no claims needed)
-    int nl, i0, nseg, kprem;        // literal additions, entry binade, binade segments, subtractions of DPI
+    int nl, i0, nseg, kprem;        // literal additions (bracket form: the period's samples), entry binade, binade segments, subtractions of DPI
     int dm[GC_CLAIM_CSEG];
     int pad[2];
+    double lo, hi;                  // bracket form: period starts (remcarr) the claims were proved for
 };
 
 GC_HD int gc_expo(double x) { return (int)((gc_d2u(x) >> 52) & 0x7FF); }
@@ -1384,10 +1388,14 @@ GC_HD void gc_code_stepc_init(GcCodeStepC<ITOP> &C, const GcCodePlan &P)
     GC_PIN_V(C.smaxci);
 }
 
-template <int ITOP, int TMAX, bool DISCOVER>
+// PERLANE: the lanes of the calling wavefront hold different periods (always so when discovering; and when the
+// discovery pass checks claims at the other end of a bracket)
+template <int ITOP, int TMAX, bool DISCOVER, bool PERLANE = DISCOVER>
 GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, double remcode, int nt, GcCodeClaims &cl,
-                               double *remcode_out)
+                               double *remcode_out, const double *dmd = nullptr)
 {
+    // dmd (evaluating a value only): the claimed counts of the climb as doubles, converted by the caller -- cl.dm is
+    // then not read by anything the value depends on
     GC_FP_STRICT
     const double ci = C.ci, dlen = C.dlen, dtop = C.d[ITOP];
     bool ok = DISCOVER || cl.tag == 1;
@@ -1432,7 +1440,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
         ys[0] = y;
 #pragma unroll
         for (int k = 0; k < GC_CLAIM_LIT; k++) ys[k + 1] = ys[k] + ci;
-        const int nlu = DISCOVER ? nl : GC_UNIFORM_INT(nl);
+        const int nlu = PERLANE ? nl : GC_UNIFORM_INT(nl);
         const bool inr = nlu >= 0 && nlu <= GC_CLAIM_LIT;
         const int ix = inr ? nlu : 0;
         const double yprev = gc_pick(ys, ix > 0 ? ix - 1 : 0);
@@ -1459,7 +1467,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
             dm = cl.dm[i];
             GC_PIN_V(dm);
         }
-        const double yl = fma((double)dm, C.d[i], y1);
+        const double yl = fma(dmd ? dmd[i] : (double)dm, C.d[i], y1);
         const double yn = yl + ci;
         // last value of the segment below the top of its binade, the next one at or above it: for the table's
         // binades (tops are powers of two, the values positive) a comparison of the exponent fields
@@ -1479,7 +1487,6 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
 #pragma unroll
         for (int i = ITOP + 1; i < 13; i++) cl.dm[i] = 0;
         cl.jsum = j;
-        cl.pad[0] = cl.pad[1] = 0;
     } else {
         j = cl.jsum;                                // (the sum the discovering run of this function formed of the same claims)
     }
@@ -1492,7 +1499,7 @@ GC_HD bool gc_code_claims_step(const GcCodePlan &P, const GcCodeStepC<ITOP> &C, 
         ys[0] = y;
 #pragma unroll
         for (int k = 0; k < TMAX; k++) ys[k + 1] = ys[k] + ci;
-        const int tu = DISCOVER ? t : GC_UNIFORM_INT(t);
+        const int tu = PERLANE ? t : GC_UNIFORM_INT(t);
         y = gc_pick(ys, (tu >= 1 && tu <= TMAX) ? tu : 0);
     }
     *remcode_out = y - C.smaxci;
@@ -1505,7 +1512,7 @@ GC_HD bool gc_code_claims_itop(const GcCodePlan &P, double remcode, int nt, GcCo
 {
     GcCodeStepC<ITOP> C;
     gc_code_stepc_init(C, P);
-    return gc_code_claims_step<ITOP, GC_CLAIM_TAIL2, DISCOVER>(P, C, remcode, nt, cl, remcode_out);     // (the widest tail: claims carry counts, not the instance)
+    return gc_code_claims_step<ITOP, GC_CLAIM_TAIL2, DISCOVER, true>(P, C, remcode, nt, cl, remcode_out);     // (the widest tail: claims carry counts, not the instance)
 }
 
 template <bool DISCOVER>
@@ -1534,7 +1541,7 @@ GC_HD bool gc_code_claims(const GcCodePlan &P, double remcode, int nt, GcCodeCla
 //               far from zero).
 // Anything else -- a start next to zero, a start below the window -- is left to the certified step and the
 // walkers.
-#define GC_CLAIM_CWIN 8
+#define GC_CLAIM_CWIN 11
 struct GcCarStepC {
     double d[GC_CLAIM_CWIN], pre[GC_CLAIM_CWIN];   // step, the tie binade's own addition (s or 0)
     double s;
@@ -1571,8 +1578,10 @@ GC_HD void gc_car_stepc_init(GcCarStepC &C, const GcCarPlan &P, int nmax)
     GC_PIN_V(C.s);
 }
 
-template <bool DISCOVER>
-GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, double remcarr, int n, GcCarClaims &cl, double *remcarr_out)
+// SHAPE (evaluating): 0 the row says which (cl.tag), 1 / 2 the caller knows it is the window / one binade
+template <bool DISCOVER, bool PERLANE = DISCOVER, int SHAPE = 0>
+GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, double remcarr, int n, GcCarClaims &cl, double *remcarr_out,
+                                  const double *dmd = nullptr)
 {
     GC_FP_STRICT
     const double s = C.s;
@@ -1589,7 +1598,7 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
         double xe;
         cl.tag = gc_one_binade_walk(x, s, n, &xe) ? 2 : 1;
     }
-    if (cl.tag == 2) {
+    if (SHAPE == 2 || (SHAPE == 0 && cl.tag == 2)) {
         if (!gc_one_binade_walk(x, s, n, &x)) { if (DISCOVER) cl.tag = 0; return false; }
     } else {
         ok = cl.tag == 1;
@@ -1631,7 +1640,7 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
             int dm = cl.dm[p];
             if (!DISCOVER) GC_PIN_V(dm);            // (stays in its vector register: the chain is short of scalar ones)
             const double x1 = x + C.pre[p];
-            const double xl = fma((double)dm, C.d[p], x1);
+            const double xl = fma(dmd ? dmd[p] : (double)dm, C.d[p], x1);
             const double xn = xl + s;
             // (magnitudes against the top of the binade, a power of two: exponent fields)
             const uint32_t ktop = (uint32_t)(C.ex0 + C.ilo + p + 1) << 20;
@@ -1662,7 +1671,7 @@ GC_HD bool gc_carrier_claims_step(const GcCarPlan &P, const GcCarStepC &C, doubl
         ps[0] = p;
 #pragma unroll
         for (int k = 0; k < GC_CLAIM_PREM; k++) ps[k + 1] = ps[k] - GC_NCO_DPI;
-        const int ku = DISCOVER ? kp : GC_UNIFORM_INT(kp);
+        const int ku = PERLANE ? kp : GC_UNIFORM_INT(kp);
         const bool inr = ku >= 0 && ku <= GC_CLAIM_PREM;
         const int ix = inr ? ku : 0;
         const double pprev = gc_pick(ps, ix > 0 ? ix - 1 : 0);

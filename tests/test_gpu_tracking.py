@@ -279,8 +279,8 @@ def test_planner_chain_long_batch(gc, orc, engine):
     engine.trk_run(nepoch)
     II, QQ, ns = engine.trk_fetch()
     fin = engine.trk_get_state()
-    # the batch form of the planner (periods discovered side by side, evaluated and checked in the chain) is
-    # what serves these channels; the certified step and the walkers take what it declines
+    # the batch form of the planner (periods discovered side by side with a bracket around their starts, evaluated in
+    # the chain) is what serves these channels; the certified step and the walkers take what it declines
     gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
     assert stats[:3].sum() >= len(chans) * nepoch and stats[3:6].sum() >= len(chans) * nepoch, stats
     assert stats[0] >= 0.95 * stats[:3].sum() and stats[3] >= 0.8 * stats[3:6].sum(), stats
@@ -289,6 +289,66 @@ def test_planner_chain_long_batch(gc, orc, engine):
     for a, b in zip(fin, ofin):
         assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
+
+
+def test_planner_brackets_hold_under_the_checks(gc, orc, engine, tmp_path):
+    """The batch planner's chain evaluates a period WITHOUT its checks when the period's exact start lies inside the
+    bracket the discovery proved the claims for (gnsscorr_plan.hip).  GNSSCORR_PLAN_VERIFY=1 makes the chain run
+    every step with the checks: over 3 batches x 16 channels x 500 periods (rising, falling, fast and slow phases,
+    the look-ahead discovery in use from the second batch on) no bracketed start may fail them, nearly every period
+    must have a bracket that holds its start, and the sums and states must equal the default run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    nepoch, nbatch = 500, 3
+    nsamples = 16368 * (nepoch * nbatch + 12)
+    script = tmp_path / "verify.py"
+    script.write_text(f"""
+import ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+import gnsscorr_loader
+gc = gnsscorr_loader.load()
+rng = np.random.default_rng(515)
+data = rng.integers(-60, 61, size=({nsamples}, 2), dtype=np.int8)
+eng = gc.Engine(0)
+eng.ring_create(1, 2, {nsamples})
+eng.ring_push_raw(1, data, {nsamples})
+chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, 17)]
+eng.set_channels(chans)
+states = [dict(carrfreq=float(rng.uniform(-9000, 9000)), codefreq=c.crate + float(rng.uniform(-6, 6)),
+               remcode=float(rng.uniform(0.01, 0.99)), remcarr=float(rng.uniform(0, 6.2)), buffloc=5 + 700 * i)
+          for i, c in enumerate(chans)]
+states[0].update(carrfreq=2200.0, codefreq=chans[0].crate, remcode=0.0, remcarr=0.0)     # fresh out of acquisition
+eng.trk_set_state(states)
+stats = np.zeros(8, dtype=np.uint64)
+gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
+sums = []
+for b in range({nbatch}):
+    eng.trk_run({nepoch})
+    II, QQ, ns = eng.trk_fetch()
+    sums.append([float(II.sum()), float(QQ.sum()), int(ns.sum()), float(np.abs(II).max())])
+fin = eng.trk_get_state()
+gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
+print(json.dumps(dict(sums=sums, fin=[[f["remcode"].hex(), f["remcarr"].hex(), int(f["buffloc"])] for f in fin], stats=stats.tolist())))
+""")
+    runs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, GNSSCORR_PLAN_VERIFY=mode)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    for mode, r in runs.items():
+        st = r["stats"]
+        total = sum(st[:3])                             # (the batch planned ahead of the last run is counted too)
+        assert total >= 16 * nepoch * nbatch and sum(st[3:6]) == total, (mode, st)
+        assert st[6] == 0, (mode, st)                   # no bracketed start failed a check
+        # the brackets hold the exact starts (channel 0's sums hit their thresholds exactly: only brackets a few ulps
+        # wide pass at both ends, and those its starts may miss -- it then takes the step with the checks)
+        assert st[7] <= total // 16 + total // 1000, (mode, st)
+        assert st[0] >= 0.93 * total and st[3] >= 0.93 * total, (mode, st)      # (channel 0 has no brackets: its sums hit every threshold exactly)
+    assert runs["0"]["sums"] == runs["1"]["sums"] and runs["0"]["fin"] == runs["1"]["fin"]
 
 
 def test_planner_chain_wide_correlator_spacing(gc, orc, engine):

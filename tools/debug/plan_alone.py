@@ -10,7 +10,8 @@ rng = np.random.default_rng(20240601)
 data = np.random.default_rng(3).integers(-60, 61, size=((E + 4) * NS, 2), dtype=np.int8)
 eng = gc.Engine(0)
 eng.ring_create(1, 2, data.shape[0]); eng.ring_push_raw(1, data, data.shape[0])
-chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, 33)]
+NCH = int(os.environ.get('NCH', '32'))
+chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, NCH + 1)]
 eng.set_channels(chans)
 st0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)), remcode=float(rng.uniform(0.01, 0.99)),
             remcarr=float(rng.uniform(0, 6.2)), buffloc=int(rng.integers(0, NS))) for c in chans]
@@ -20,4 +21,12 @@ for rep in range(4):
     eng.timing_reset()
     eng.trk_run(E)
     eng.sync()
-    print({k: round(eng.timing_read(k)[0] / max(eng.timing_read(k)[1], 1), 4) for k in ("trk_spec", "trk_plan", "trk_expand", "trk_edges", "trk_corr")})
+    print(NCH, {k: round(eng.timing_read(k)[0] / max(eng.timing_read(k)[1], 1), 4) for k in ("trk_spec", "trk_plan", "trk_expand", "trk_edges", "trk_corr")})
+if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):
+    import ctypes
+    pp = np.zeros(64 * 16, dtype=np.uint64)
+    gc.lib().gnsscorr_debug_plan_prof(ctypes.c_void_p(pp.ctypes.data))
+    pp = pp.reshape(64, 2, 8)[:NCH].astype(np.float64) / 4
+    for ch in range(min(NCH, 4)):
+        print("  ch %d carrfreq %.1f code loop %.0f slow %.0f rows %.0f | carrier loop %.0f slow %.0f (%.1f) rows %.0f n %.0f" % (
+            ch, st0[ch]["carrfreq"], pp[ch, 0, 0], pp[ch, 0, 1], pp[ch, 0, 2], pp[ch, 1, 0], pp[ch, 1, 1], pp[ch, 1, 4], pp[ch, 1, 2], pp[ch, 1, 3]))
