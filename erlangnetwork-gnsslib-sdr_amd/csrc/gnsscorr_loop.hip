@@ -358,6 +358,33 @@ __device__ __attribute__((noinline)) double tail_code_slow(double ci, double rem
     return gc_code_rem(cend, smax, ci);
 }
 
+// the step WITH its checks, for a period whose start lies outside the bracket its claims were proved for (rare): out
+// of line, so that the chains' loops carry the value form only.  PC / PK / cl: the workgroup's tables and rows (LDS).
+template <int IT>
+__device__ __attribute__((noinline)) bool tail_code_checked(const GcCodePlan *PC, double remcode, int nt, int tcls, const GcCodeClaims *cl, double *out)
+{
+    GcCodeStepC<IT> SC;
+    gc_code_stepc_init(SC, *PC);
+    GcCodeClaims c2 = *cl;
+    double r;
+    bool ok;
+    if (tcls == 0) ok = gc_code_claims_step<IT, 8, false, true>(*PC, SC, remcode, nt, c2, &r);
+    else if (tcls == 1) ok = gc_code_claims_step<IT, GC_CLAIM_TAIL, false, true>(*PC, SC, remcode, nt, c2, &r);
+    else ok = gc_code_claims_step<IT, GC_CLAIM_TAIL2, false, true>(*PC, SC, remcode, nt, c2, &r);
+    if (ok) *out = r;
+    return ok;
+}
+__device__ __attribute__((noinline)) bool tail_carrier_checked(const GcCarPlan *PK, int nsamp, double remcarr, int n, const GcCarClaims *cl, double *out)
+{
+    GcCarStepC CK;
+    gc_car_stepc_init(CK, *PK, nsamp + 16);
+    GcCarClaims c2 = *cl;
+    double r;
+    const bool ok = gc_carrier_claims_step<false, true>(*PK, CK, remcarr, n, c2, &r);
+    if (ok) *out = r;
+    return ok;
+}
+
 #define GC_TAIL_NW 8            // wavefronts of the tail workgroup
 struct TailShared {
     gnsscorr_loop_t lp;
@@ -570,34 +597,86 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
     __syncthreads();
     GC_TSTAMP(3);       // step tables
     if (want > 1) {
-        // the structure of the interval's periods from their closed-form starts (gc_spec_start), one lane per period:
-        // what trk_spec_kernel does for a batch.  The chain below evaluates and checks them; a period whose claims do
-        // not hold takes the certified step.
-        if (wave == 2 && lane < want) {
+        // The structure of the interval's periods from their closed-form starts (gc_spec_start), proved for a bracket
+        // around each start as the batch planner's discovery does (gnsscorr_plan.hip): lane e discovers the claims of
+        // period e from the bracket's lower end, lane 32 + e from its upper end; where both ends pass their checks with
+        // the same claims and the same sample count, every start in between does (every operation of the step is
+        // monotone in the start), and the chain below evaluates such a period without the checks.  The closed form
+        // reaches at most GC_STEP_KMAX periods from the interval's exact start: +-2^-25 holds what its missing rounding
+        // adds up to (< 1e-8).  A period without a bracket takes the step with its checks, then the certified step.
+        const double W = 2.98023223876953125e-8;         // 2^-25
+        const bool mine = lane < want || (lane >= 32 && lane - 32 < want);
+        const int pe = lane & 31;
+        const bool hiend = lane >= 32;
+        if (wave == 2 && mine) {
             GcCodeClaims cc;
             cc.tag = 0;
+            cc.n = cc.pad = 0;
+            cc.lo = cc.hi = 0.0;
+            bool ok = false;
+            int n = 0, side = 0;
+            double end = 0.0;
             if (shape_ok && spc > 1e-300 && spc < 1e300) {
                 double rc, rk, dummy;
-                int n;
-                gc_spec_start(S.remcode[0], S.remcarr[0], ci, spc, ps, dlen, lane, &rc, &rk, &n);
-                if (n > 0 && n <= (1 << 24)) gc_code_claims<true>(S.PC, rc, n + 2 * c.smax, cc, &dummy);
+                int nhat;
+                gc_spec_start(S.remcode[0], S.remcarr[0], ci, spc, ps, dlen, pe, &rc, &rk, &nhat);
+                end = hiend ? rc + W : rc - W;
+                const double q = __ddiv_rn(__dsub_rn(dlen, end), spc);           // ref src/sdrtrk.c:31-32
+                n = (q > -2147483648.0 && q < 2147483648.0) ? (int)q : 0;
+                side = end - S.PC.smaxci < 0.0 ? 1 : 0;                          // (ref src/sdrcmn.c:614: one branch for the whole bracket)
+                if (n > 0 && n <= (1 << 24)) ok = gc_code_claims<true>(S.PC, end, n + 2 * c.smax, cc, &dummy);
             }
-            S.ccl[lane] = cc;
+            bool same = ok && __shfl(ok ? 1 : 0, lane ^ 32, 64) != 0;
+            same = same && n == __shfl(n, lane ^ 32, 64) && side == __shfl(side, lane ^ 32, 64);
+            same = same && cc.i0 == __shfl(cc.i0, lane ^ 32, 64) && cc.q == __shfl(cc.q, lane ^ 32, 64) &&
+                   cc.nl == __shfl(cc.nl, lane ^ 32, 64) && cc.jsum == __shfl(cc.jsum, lane ^ 32, 64);
+#pragma unroll
+            for (int i = 0; i < 13; i++) same = same && cc.dm[i] == __shfl(cc.dm[i], lane ^ 32, 64);
+            const double other = __shfl(end, lane ^ 32, 64);
+            if (!hiend) {
+                cc.tag = same ? 1 : 0;
+                cc.n = n;
+                cc.lo = end;
+                cc.hi = other;
+                S.ccl[pe] = cc;
+            }
         }
-        if (wave == 3 && lane < want) {
+        if (wave == 3 && mine) {
             GcCarClaims ck;
             ck.tag = 0;
+            ck.nl = ck.i0 = ck.nseg = ck.kprem = 0;
+            ck.pad[0] = ck.pad[1] = 0;
+            ck.lo = ck.hi = 0.0;
+#pragma unroll
+            for (int i = 0; i < GC_CLAIM_CSEG; i++) ck.dm[i] = 0;
+            bool ok = false;
+            int n = 0;
+            double end = 0.0;
             if (shape_ok && spc > 1e-300 && spc < 1e300) {
                 double rc, rk, dummy;
-                int n;
-                gc_spec_start(S.remcode[0], S.remcarr[0], ci, spc, ps, dlen, lane, &rc, &rk, &n);
+                gc_spec_start(S.remcode[0], S.remcarr[0], ci, spc, ps, dlen, pe, &rc, &rk, &n);
+                end = hiend ? rk + W : rk - W;
                 if (n > 0 && n <= (1 << 24)) {
                     GcCarStepC CK;
                     gc_car_stepc_init(CK, S.PK, c.nsamp + 16);
-                    gc_carrier_claims_step<true>(S.PK, CK, rk, n, ck, &dummy);
+                    ok = gc_carrier_claims_step<true>(S.PK, CK, end, n, ck, &dummy);
                 }
             }
-            S.kcl[lane] = ck;
+            bool same = ok && __shfl(ok ? 1 : 0, lane ^ 32, 64) != 0;
+            same = same && ck.tag == __shfl(ck.tag, lane ^ 32, 64) && ck.nl == __shfl(ck.nl, lane ^ 32, 64) &&
+                   ck.i0 == __shfl(ck.i0, lane ^ 32, 64) && ck.nseg == __shfl(ck.nseg, lane ^ 32, 64) &&
+                   ck.kprem == __shfl(ck.kprem, lane ^ 32, 64);
+#pragma unroll
+            for (int i = 0; i < GC_CLAIM_CSEG; i++) same = same && ck.dm[i] == __shfl(ck.dm[i], lane ^ 32, 64);
+            const double other = __shfl(end, lane ^ 32, 64);
+            if (!hiend) {
+                // (tag 2, a period inside one binade, carries its own conditions and is judged by them: it needs no bracket)
+                ck.tag = same ? ck.tag : (ok && ck.tag == 2 ? 2 : 0);
+                ck.nl = n;
+                ck.lo = end;
+                ck.hi = other;
+                S.kcl[pe] = ck;
+            }
         }
         __syncthreads();
     }
@@ -642,14 +721,21 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                         tail_wave_sync();
                         if (lane == 0) __hip_atomic_store(&S.prog, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (valid) {
-                            double r;
+                            double r = remcode;
                             GcCodeClaims cl = S.ccl[e];
                             const int nt = n + 2 * c.smax;
-                            bool ok = false;
-                            if (inst) {
-                                if (tcls == 0) ok = gc_code_claims_step<IT, 8, false>(S.PC, SC, remcode, nt, cl, &r);
-                                else if (tcls == 1) ok = gc_code_claims_step<IT, GC_CLAIM_TAIL, false>(S.PC, SC, remcode, nt, cl, &r);
-                                else ok = gc_code_claims_step<IT, GC_CLAIM_TAIL2, false>(S.PC, SC, remcode, nt, cl, &r);
+                            // the exact start inside the bracket the claims were proved for: the values alone (the step's
+                            // verdict is unused, the compiler drops the checks); else the step with its checks
+                            const bool inside = __builtin_amdgcn_readfirstlane((inst && cl.tag == 1 && remcode >= cl.lo && remcode <= cl.hi && n == cl.n) ? 1 : 0) != 0;
+                            bool ok = inside;
+                            if (inside) {
+                                if (tcls == 0) (void)gc_code_claims_step<IT, 8, false>(S.PC, SC, remcode, nt, cl, &r);
+                                else if (tcls == 1) (void)gc_code_claims_step<IT, GC_CLAIM_TAIL, false>(S.PC, SC, remcode, nt, cl, &r);
+                                else (void)gc_code_claims_step<IT, GC_CLAIM_TAIL2, false>(S.PC, SC, remcode, nt, cl, &r);
+                            } else if (inst && cl.tag == 1) {
+                                double r2;
+                                ok = tail_code_checked<IT>(&S.PC, remcode, nt, tcls, &S.ccl[e], &r2);
+                                if (ok) r = r2;
                             }
                             if (ok) remcode = r;
                             else if (gc_code_period(S.PC, remcode, nt, fill, &r, ne)) remcode = r;
@@ -686,9 +772,23 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                 if (pg == 0x7fffffff && e >= S.k) break;
                 const int n = S.n[e];
                 if (S.valid[e]) {
-                    double r;
+                    double r = remcarr;
                     GcCarClaims cl = S.kcl[e];
-                    if (gc_carrier_claims_step<false>(S.PK, CK, remcarr, n, cl, &r)) remcarr = r;
+                    const int tagu = __builtin_amdgcn_readfirstlane(cl.tag);
+                    const bool inside = __builtin_amdgcn_readfirstlane((tagu == 1 && remcarr >= cl.lo && remcarr <= cl.hi && n == cl.nl) ? 1 : 0) != 0;
+                    bool ok = inside;
+                    if (inside) {
+                        (void)gc_carrier_claims_step<false, false, 1>(S.PK, CK, remcarr, n, cl, &r);      // the values alone: the bracket is the proof
+                    } else if (tagu == 2) {
+                        double r2 = remcarr;
+                        ok = gc_carrier_claims_step<false, false, 2>(S.PK, CK, remcarr, n, cl, &r2);       // (its own conditions, checked)
+                        if (ok) r = r2;
+                    } else if (tagu == 1) {
+                        double r2;
+                        ok = tail_carrier_checked(&S.PK, c.nsamp, remcarr, n, &S.kcl[e], &r2);
+                        if (ok) r = r2;
+                    }
+                    if (ok) remcarr = r;
                     else if (gc_carrier_period(S.PK, remcarr, n, fill, &r, ne)) remcarr = r;
                     else remcarr = tail_carrier_slow(ps, remcarr, n, ne);
                 }
