@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=1000, help="code periods per channel per launch")
     ap.add_argument("--inner", type=int, default=32, help="launches per step (so that 20 steps time >= 0.5 s)")
-    ap.add_argument("--loop-periods", type=int, default=400, help="periods of the closed-loop legs")
+    ap.add_argument("--loop-periods", type=int, default=2000, help="periods of the closed-loop legs (2 s of signal: a synchronised channel's first interval is partial)")
     ap.add_argument("--acq-steps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-acq", action="store_true", help="skip the acquisition leg")
