@@ -1270,15 +1270,20 @@ GC_HD void gc_spec_start(double remcode0, double remcarr0, double ci, double spc
 //             steps the head takes, how many of the reference's own additions follow next to zero, how many
 //             equal steps each binade takes, how many subtractions the phase remainder needs -- integers,
 //             the "claims" of the period;
-//   evaluate  (the sequential chain: trk_plan2_kernel) runs the step from the exact period start as one
-//             fixed, branch-free sequence of positions -- literal additions whose addend is the step or
-//             zero, binade segments y -> fma(dm, d, y + pre) + step -- with the claims as its data, and
-//             checks every claim against the values it produces: a segment's last value below the top of
-//             its binade and its successor at or above, a literal addition only below the table, the
-//             period's samples adding up.  The checks are the definitions of the claimed numbers, so a
-//             step that passes them has produced the reference's values; one that fails them (the
-//             closed-form start was a rounding away from the truth: a few periods in ten thousand) returns
-//             false and the caller takes the certified step above, then the walkers.
+//   evaluate  (the sequential chain: trk_plan4_kernel, and the closed loop's tail) runs the step from the exact
+//             period start as one fixed, branch-free sequence of positions -- literal additions whose addend is
+//             the step or zero, binade segments y -> fma(dm, d, y + pre) + step -- with the claims as its data.
+//             The same function checks every claim against the values it produces: a segment's last value below
+//             the top of its binade and its successor at or above, a literal addition only below the table, the
+//             period's samples adding up.  The checks are the definitions of the claimed numbers, so a step that
+//             passes them has produced the reference's values.
+//   who checks   every operation of the step is monotone in the period's start and every check compares such a
+//             value with a constant, so claims that pass from both ends of an interval of starts pass from every
+//             start inside it: the discovery runs the checks at the ends of a bracket around its estimate of the
+//             start (gnsscorr_plan.hip, trk_spec_kernel), and a chain whose exact start lies inside the bracket
+//             calls the step with its verdict unused -- the compiler then drops the checks and the values
+//             remain.  A start outside its bracket takes the step with its checks, then the certified step
+//             above, then the walkers.
 //
 // Both are the same function (template parameter DISCOVER), so there is one statement of the step's shape.
 // In the binade where the addend is a tie (at most one) the segment always starts with one of the

@@ -1,5 +1,5 @@
 // What one period of the planner's evaluating chain costs a lone wavefront: the code / carrier step on claims with
-// its checks (as trk_plan2 runs it), and the same step with only the VALUE kept (the checks' result unused: the
+// its checks (as round 2's chain ran it), and the same step with only the VALUE kept (the checks' result unused: the
 // compiler drops them) -- the split behind "one wavefront chains the values, others check them".
 // hipcc -O3 --offload-arch=gfx950 -I../../erlangnetwork-gnsslib-sdr_amd/csrc claims_chain.hip -o claims_chain
 #include <hip/hip_runtime.h>
