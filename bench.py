@@ -385,6 +385,34 @@ def main():
                                   "trk_corr": k_ms / max(k_n, 1), "trk_finish": s_ms / max(s_n, 1)},
     }
 
+    # ---- host-fed leg through the sharded driver (any N): rank 0 owns the IF stream in pinned HOST memory; every
+    # batch's chunk is copied into rank 0's ring slot and broadcast from there into every rank's ring (RCCL), two chunks
+    # ahead of the batch that reads it.  The PCIe- and xGMI-inclusive rate of the multi-GPU data path; never `value`.
+    if not os.environ.get("BENCH_NO_HOSTFED"):
+        log("host-fed leg through the sharded driver")
+        chunk_host = torch.from_numpy(np.ascontiguousarray(data.reshape(-1))).pin_memory() if rank == 0 else None
+        nl = 12
+        for _ in range(3):                  # warm-up (the first feeds overwrite the resident chunks with the same samples)
+            se.step(E, chunk_host, resident=False)
+        se.wait()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nl):
+            se.step(E, chunk_host, resident=False)
+        se.wait()
+        barrier()
+        sdt = time.perf_counter() - t0
+        if dist is not None:
+            tt_ = torch.tensor([sdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            sdt = float(tt_.item())
+        eng.trk_fetch()                     # (raises on a ring violation: every batch found its chunk in the ring)
+        out["host_fed_sharded"] = {"x_realtime": nl * E / sdt / 1000.0, "correlations_per_s": world * NCH * E * nl * ntap / sdt,
+                                   "host_to_ring_GBps": nl * chunk * 2 / sdt / 1e9, "n_gpus": world,
+                                   "note": "ShardedEngine.step(..., resident=False): rank 0 copies every launch's IF chunk "
+                                           "(32.7 MB) from pinned host memory into its ring slot, broadcasts it into every rank's "
+                                           "ring two chunks ahead, each rank tracks its own channels"}
+
     # ---- closed loop (pll/dll on the device), same channels ----------------
     if world == 1 and args.loop_periods > 0:
         NP = args.loop_periods
