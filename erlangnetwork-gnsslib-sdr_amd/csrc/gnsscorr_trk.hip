@@ -33,12 +33,109 @@ namespace {
 // ---------------------------------------------------------------------------
 // One lane per (channel, epoch): ring offset, the two NCOs of the period as piece tables, and per
 // round of the correlator the chip edges its samples can touch.
-__global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
+// trk_expand's emitters.  A lane builds its unit's tables alone, and what bounds it is the latency of memory operations
+// that depend on each other, not arithmetic: so the tables go to global memory by stores alone (the piece being built
+// stays in registers; the generic emitters of gnsscorr_nco.h read the previous piece back for every new one), their
+// invariants are checked as they are emitted, and the five fields the rounds' searches need stay in LDS (lane-strided).
+#define GC_EXP_LANES 64
+struct ExpCarTable {
+    int *k0;
+    GcCarSeg *seg;
+    int cap, n, overflow, prevk;
+    bool lastzero, bad;             // bad: the pieces do not start at sample 0 / at increasing samples
+    __device__ void operator()(int k, double x, double d, int /*count*/)
+    {
+        const GcCarSeg s = gc_carseg_make(x, d);
+        const bool zero = s.fx == 0 && s.dfx == 0;
+        if (n > 0 && zero && lastzero) return;      // (adjacent all-zero pieces are one piece, as GcCarTable)
+        if (n >= cap) { overflow = 1; return; }
+        bad = bad || (n == 0 ? k != 0 : !(prevk < k));
+        k0[n] = k;
+        seg[n] = s;
+        prevk = k;
+        lastzero = zero;
+        n++;
+    }
+};
+struct ExpCodeLds {                 // [piece][lane]
+    int j0[GC_NCODE * GC_EXP_LANES], cnt[GC_NCODE * GC_EXP_LANES], w[GC_NCODE * GC_EXP_LANES];
+    double y0[GC_NCODE * GC_EXP_LANES], d[GC_NCODE * GC_EXP_LANES];
+};
+struct ExpCodeTable {
+    GcCodeSeg *seg;
+    ExpCodeLds *lds;
+    int lane, cap, n, overflow, prev_end;
+    bool bad;                       // bad: an empty piece, or pieces that do not follow each other
+    double py0, pd, pinv, pyl;      // the piece being built (piece n - 1) ...
+    int pj0, pcnt, pw;
+    __device__ void flush()         // ... is complete
+    {
+        GcCodeSeg s;
+        s.y0 = py0; s.d = pd; s.inv = pinv; s.ylast = pyl; s.j0 = pj0; s.cnt = pcnt; s.w = pw; s.pad = 0;
+        seg[n - 1] = s;
+        const int x = (n - 1) * GC_EXP_LANES + lane;
+        lds->j0[x] = pj0; lds->cnt[x] = pcnt; lds->w[x] = pw; lds->y0[x] = py0; lds->d[x] = pd;
+        bad = bad || pcnt <= 0 || (n > 1 && prev_end != pj0);
+        prev_end = pj0 + pcnt;
+    }
+    __device__ void operator()(int j, double y, double d, int count, int w)
+    {
+        GC_FP_STRICT
+        const double yl = fma((double)(count - 1), d, y);
+        // (positions inside chip 0 after a wrap join the piece before them, as GcCodeTable)
+        if (n > 0 && pw == w && py0 > -1.0 && pyl < 1.0 && y > -1.0 && yl < 1.0) {
+            pcnt += count;
+            pyl = yl;
+            pd = 0.0;
+            pinv = 0.0;
+            return;
+        }
+        if (n >= cap) { overflow = 1; return; }
+        if (n > 0) flush();
+        py0 = y;
+        pd = count > 1 ? d : 0.0;
+        pinv = (count > 1 && d != 0.0) ? 1.0 / d : 0.0;
+        pyl = yl;
+        pj0 = j;
+        pcnt = count;
+        pw = w;
+        n++;
+    }
+    __device__ void finish(int nt)  // the last piece; the pieces cover the nt replica positions
+    {
+        if (n > 0) {
+            flush();
+            bad = bad || prev_end != nt;
+        }
+    }
+    // gc_code_chip_at on the LDS copy
+    __device__ int chip_at(int j, int *w, int *piece) const
+    {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {                            // last piece with j0 <= j
+            const int mid = (lo + hi + 1) >> 1;
+            if (lds->j0[mid * GC_EXP_LANES + lane] <= j) lo = mid; else hi = mid - 1;
+        }
+        const int x = lo * GC_EXP_LANES + lane;
+        if (w) *w = lds->w[x];
+        if (piece) *piece = lo;
+        int i = j - lds->j0[x];
+        const int cnt = lds->cnt[x];
+        if (i < 0) i = 0;
+        if (i >= cnt) i = cnt - 1;
+        const double d = lds->d[x], y0 = lds->y0[x];
+        if (d == 0.0) return (int)y0;
+        return (int)fma((double)i, d, y0);
+    }
+};
+
+__global__ __launch_bounds__(GC_EXP_LANES) void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPlan *__restrict__ plan,
                                   GcTrkUnit *__restrict__ unit, GcUnitSegs *__restrict__ segs,
                                   int *__restrict__ nsamp_out, int nch, int nepoch,
                                   GcRound *__restrict__ rounds, int nseg, int max_n, int nit,
                                   int *__restrict__ nco_overflow)
 {
+    __shared__ ExpCodeLds slds;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nch * nepoch) return;
     const GcChan &c = chan[i / nepoch];
@@ -64,38 +161,32 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
         unit[i] = u;
         return;
     }
-    GcCarTable ct{sg->carK0, sg->car, GC_NCAR, 0, 0};
-    GcCodeTable dt{sg->code, GC_NCODE, 0, 0};
+    ExpCarTable ct{sg->carK0, sg->car, GC_NCAR, 0, 0, 0, false, false};
+    ExpCodeTable dt{sg->code, &slds, (int)threadIdx.x, GC_NCODE, 0, 0, 0, false, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
     {
         GcNcoFast f;
         gc_fast_init(f, gc_carrier_ps(p.carrfreq, c.ti));
         gc_fast_carrier_walk(f, gc_carrier_phis(p.phi0), p.n, ct);
         gc_fast_init(f, ci);
         gc_fast_code_walk(f, gc_code_start(p.coff, c.smax, ci, c.clen), c.clen, u.nt, dt);
+        dt.finish(u.nt);
     }
     u.ncar = ct.n;
     u.ncode = dt.n;
     // what the correlator's scans rely on: carrier pieces start at sample 0 and at increasing samples, code pieces
     // are non-empty, contiguous and cover the nt replica positions (anything else is reported, never correlated)
-    bool bad = ct.overflow || dt.overflow || ct.n < 1 || dt.n < 1;
-    if (!bad) {
-        bad = sg->carK0[0] != 0;
-        for (int q = 0; q + 1 < ct.n; q++) bad = bad || !(sg->carK0[q] < sg->carK0[q + 1]);
-        for (int q = 0; q < dt.n; q++)
-            bad = bad || sg->code[q].cnt <= 0 || sg->code[q].j0 + sg->code[q].cnt != (q + 1 < dt.n ? sg->code[q + 1].j0 : u.nt);
-    }
+    const bool bad = ct.overflow || dt.overflow || ct.n < 1 || dt.n < 1 || ct.bad || dt.bad;
     if (bad) {
         if (nco_overflow) atomicAdd(nco_overflow, 1);
         u.n = 0;
         unit[i] = u;
         return;
     }
-    unit[i] = u;
 
     // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel): round r of workgroup
     // seg covers samples [kl, kl + rsamp) of the period and can touch the chips T(first sample) ..
     // T(last sample + 2 smax); rank[] turns those into positions in the code's edge list
-    if (!rounds) return;
+    if (!rounds) { unit[i] = u; return; }
     const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
     const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
     const unsigned short *rank = (const unsigned short *)(c.code + 1024);
@@ -109,8 +200,8 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
             const int kfirst = kl > 0 ? kl : 0;
             const int kend = (kl + rsamp < p.n ? kl + rsamp : p.n);
             int wa = 0, wb = 0, hint = 0;
-            const int ma = gc_code_chip_at(sg->code, dt.n, kfirst, &wa, &hint);
-            const int mb = gc_code_chip_at(sg->code, dt.n, kend - 1 + 2 * c.smax, &wb, nullptr);
+            const int ma = dt.chip_at(kfirst, &wa, &hint);
+            const int mb = dt.chip_at(kend - 1 + 2 * c.smax, &wb, nullptr);
             GcRound ro;
             ro.q0 = wa * c.nedge + (int)rank[ma];
             ro.q1 = wb * c.nedge + (int)rank[mb];
@@ -125,9 +216,10 @@ __global__ void trk_expand_kernel(const GcChan *__restrict__ chan, const GcTrkPl
     // the edges whose start samples trk_edges tabulates (a period longer than the table, or replica positions
     // beyond 16 bits: the correlator finds them itself)
     if (eq1 > eq0 && eq1 - eq0 <= GC_EDGTAB && u.nt < 65535) {
-        unit[i].eq0 = eq0;
-        unit[i].eq1 = eq1;
+        u.eq0 = eq0;
+        u.eq1 = eq1;
     }
+    unit[i] = u;
 }
 
 // ---------------------------------------------------------------------------
