@@ -225,6 +225,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     uint4 vA[NIT], vB[NIT];
     GC_PSTAMP(1);                                       // unit and channel constants are here
     load_round(0, vA);                                  // in flight while the tables are set up
+    GcRound ronext = myrounds[0];                       // (likewise; every round asks for the next one's record)
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
     // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
@@ -295,11 +296,16 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         int tl = tid;
         asm volatile("" : "+v"(tl));
         if (r + 1 < nround) load_round(r + 1, vnext);
-        const GcRound ro = myrounds[r];
+        // (the round's record was asked for a round ago: nothing here waits for memory it has just requested)
+        const GcRound ro = ronext;
+        if (r + 1 < nround) ronext = myrounds[r + 1];
         const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0, rhint = ro.hint;
-        int q = rq0 + tl, ew = 0, ed = 0;
+        int q = rq0 + tl, ew = 0, ed = 0, jsraw = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
-        if (q < q1) ed = edge_load(q, rw0, &ew);       // in flight during the mixing phase
+        if (q < q1) {                                   // in flight during the mixing phase
+            ed = edge_load(q, rw0, &ew);
+            if (have_etab) jsraw = (int)etab_u[q - u.eq0];
+        }
         busy = busy || (rq0 + wv * 64 < q1);
         const int kl = klo + r * RSAMP;
 
@@ -390,7 +396,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         if (!(ablate & 2)) { if (onepiece) run(std::false_type{}); else run(std::true_type{}); }
         if (r == 0) GC_PSTAMP(4);                       // round 0: mixing done
         // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
-        if (q < q1) js = edge_js(q, ed, ew, rhint) - roff;
+        if (q < q1) js = (have_etab ? jsraw : edge_js(q, ed, ew, rhint)) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
         // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
         // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
