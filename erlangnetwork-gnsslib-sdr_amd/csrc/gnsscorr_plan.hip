@@ -512,11 +512,11 @@ __device__ __attribute__((noinline)) int plan2_car_slow(double ps_, double remca
 
 #ifdef GC_PLAN_PROF     // (tools/debug) per channel and chain: clocks in the loop, in the slow path, waiting for rows, waiting for n; slow periods
 __device__ unsigned long long gc_plan_prof[64 * 16];
-#define GC_PP_DECL unsigned long long pp_[5] = {0, 0, 0, 0, 0}
+#define GC_PP_DECL unsigned long long pp_[7] = {0, 0, 0, 0, 0, 0, 0}
 #define GC_PP_T0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define GC_PP_ADD(k, v) pp_[k] += __builtin_readcyclecounter() - (v)
 #define GC_PP_INC(k) pp_[k] += 1
-#define GC_PP_OUT(which) do { if (lane == 0 && blockIdx.x < 64) for (int k_ = 0; k_ < 5; k_++) atomicAdd(&gc_plan_prof[blockIdx.x * 16 + (which) * 8 + k_], pp_[k_]); } while (0)
+#define GC_PP_OUT(which) do { if (lane == 0 && blockIdx.x < 64) for (int k_ = 0; k_ < 7; k_++) atomicAdd(&gc_plan_prof[blockIdx.x * 16 + (which) * 8 + k_], pp_[k_]); } while (0)
 #else
 #define GC_PP_DECL do { } while (0)
 #define GC_PP_T0(v) do { } while (0)
@@ -753,6 +753,7 @@ __device__ __attribute__((noinline)) void plan4_car_wave(double ps_, int nsamp_,
         const GC_CONST gc_v4i *rows = (const GC_CONST gc_v4i *)J.claims_car + (size_t)e0 * (GC_CLAIM_ROW / 4);
         GcCarClaims row = plan4_car_row(rows);
         for (int i = 0; i < nb; i++) {
+            GC_PP_T0(ptop_);
             if (seen <= e0 + i) {
                 GC_PP_T0(pn_);
                 while (seen <= e0 + i) {
@@ -785,6 +786,8 @@ __device__ __attribute__((noinline)) void plan4_car_wave(double ps_, int nsamp_,
             if (i + 1 < nb) row = plan4_car_row(rows + (i + 1) * (GC_CLAIM_ROW / 4));       // (in flight during this period's step)
             __builtin_amdgcn_sched_barrier(0);
             if (lane == 0) g_plan4.vstart[1][i] = remcarr;
+            GC_PP_ADD(5, ptop_);
+            GC_PP_T0(pstep_);
             if (n > 0 && n <= (1 << 24)) {
                 double rp = remcarr;
                 bool done = false;
@@ -816,6 +819,7 @@ __device__ __attribute__((noinline)) void plan4_car_wave(double ps_, int nsamp_,
                 }
                 remcarr = rp;
             }
+            GC_PP_ADD(6, pstep_);
         }
         if (lane < nb) out[e0 + lane].phi0 = g_plan4.vstart[1][lane];
     }

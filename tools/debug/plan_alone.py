@@ -28,5 +28,5 @@ if hasattr(gc.lib(), "gnsscorr_debug_plan_prof"):
     gc.lib().gnsscorr_debug_plan_prof(ctypes.c_void_p(pp.ctypes.data))
     pp = pp.reshape(64, 2, 8)[:NCH].astype(np.float64) / 4
     for ch in range(min(NCH, 4)):
-        print("  ch %d carrfreq %.1f code loop %.0f slow %.0f rows %.0f | carrier loop %.0f slow %.0f (%.1f) rows %.0f n %.0f" % (
-            ch, st0[ch]["carrfreq"], pp[ch, 0, 0], pp[ch, 0, 1], pp[ch, 0, 2], pp[ch, 1, 0], pp[ch, 1, 1], pp[ch, 1, 4], pp[ch, 1, 2], pp[ch, 1, 3]))
+        print("  ch %d carrfreq %.1f code loop %.0f slow %.0f | carrier loop %.0f slow %.0f (%.1f periods) waiting for n %.0f; per period: top %.0f step %.0f" % (
+            ch, st0[ch]["carrfreq"], pp[ch, 0, 0], pp[ch, 0, 1], pp[ch, 1, 0], pp[ch, 1, 1], pp[ch, 1, 4], pp[ch, 1, 3], pp[ch, 1, 5] / 1000, pp[ch, 1, 6] / 1000))
