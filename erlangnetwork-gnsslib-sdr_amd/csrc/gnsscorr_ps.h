@@ -145,6 +145,16 @@ struct PsLayout {
     static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
 };
 
+// a . b over four int8 lanes + c into a NEW register (the three-operand form, by name: through the builtin the compiler
+// picks the accumulate-in-place form and copies the accumulator first -- every running sum of phase A is stored, so
+// that is two extra moves per sample)
+__device__ __forceinline__ int dot4_run(int a, int b, int c)
+{
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over the 64 lanes
 {
     v = dpp_add<0x111, 0xF>(v);
@@ -385,8 +395,8 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
 #pragma unroll
                 for (int i = 0; i < SPG; i++) {
                     const unsigned wd = w[DTYPE == 2 ? i >> 1 : i >> 2];
-                    aI = __builtin_amdgcn_sdot4((int)wd, (int)l[i].x, aI, false);
-                    aQ = __builtin_amdgcn_sdot4((int)wd, (int)l[i].y, aQ, false);
+                    aI = dot4_run((int)wd, (int)l[i].x, aI);
+                    aQ = dot4_run((int)wd, (int)l[i].y, aQ);
                     const int p = it * SPG + i + 1;
                     if (p < LSP) loc[tl * LPAD + p] = make_int2(aI, aQ);
                 }
