@@ -71,6 +71,36 @@ class TrkLog(C.Structure):
                  ("navbit", C.c_int)])
 
 
+class ObsState(C.Structure):
+    """gnsscorr_obs_t: what setobsdata() carries from call to call (ref src/sdrtrk.c:160-209)."""
+    _fields_ = ([(n, C.c_double) for n in ("f_sf", "f_if", "foffset", "ctime")] + [("loopms", C.c_int)] +
+                [("flagsyncf", C.c_int), ("polarity", C.c_int), ("firstsftow", C.c_double), ("firstsfcnt", C.c_uint64)] +
+                [(n, C.c_double) for n in ("L", "Isum", "sumI0", "oldremcode")] +
+                [("flagremcarradd", C.c_int), ("flagpolarityadd", C.c_int), ("loopcnt", C.c_uint64)])
+
+
+class ObsRow(C.Structure):
+    """gnsscorr_obsrow_t: element [0] of the observable histories after one call of setobsdata()."""
+    _fields_ = ([(n, C.c_double) for n in ("tow", "remcout", "L", "D", "S")] + [("codei", C.c_uint64), ("cntout", C.c_uint64),
+                ("snr", C.c_int), ("pad", C.c_int)])
+
+
+def obs_replay(state, log_rows, II0, cnt0=0):
+    """setobsdata() over one channel's log rows (numpy array of TrkLog) and its per-period trk.II[0]: returns the rows
+    of observables (numpy array of ObsRow); `state` (ObsState) is updated.  Host code only."""
+    L = lib()
+    L.gnsscorr_obs_replay.restype = C.c_int
+    L.gnsscorr_obs_replay.argtypes = [C.POINTER(ObsState), C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+    log_rows = np.ascontiguousarray(log_rows)
+    II0 = np.ascontiguousarray(II0, dtype=np.float64)
+    n = int(log_rows.shape[0])
+    out = np.zeros(max(n, 1), dtype=np.dtype(ObsRow))
+    k = L.gnsscorr_obs_replay(C.byref(state), log_rows.ctypes.data, II0.ctypes.data, n, int(cnt0), out.ctypes.data, n)
+    if k < 0:
+        raise RuntimeError("gnsscorr_obs_replay: error %d" % k)
+    return out[:k]
+
+
 class AcqRes(C.Structure):
     _fields_ = [("acqcodei", C.c_int), ("freqi", C.c_int), ("acqfreq", C.c_double),
                 ("cn0", C.c_double), ("peakr", C.c_double), ("flagacq", C.c_int),

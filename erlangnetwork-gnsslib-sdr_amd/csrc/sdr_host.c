@@ -470,6 +470,87 @@ void clearcumsumcorr(sdrtrk_t *trk)
         trk->oldsumI[i] = trk->oldsumQ[i] = trk->sumI[i] = trk->sumQ[i] = 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* observables: ref src/sdrtrk.c:160-209                                     */
+/* ------------------------------------------------------------------------- */
+/* the histories move down by one; entry 0 keeps its value (what the reference's shiftdata() through a temporary
+ * amounts to, ref src/sdrcmn.c:587-596): L[0] therefore accumulates from call to call */
+static void obs_age_d(double *h) { memmove(h + 1, h, sizeof(double) * (OBSINTERPN - 1)); }
+static void obs_age_u(uint64_t *h) { memmove(h + 1, h, sizeof(uint64_t) * (OBSINTERPN - 1)); }
+
+void setobsdata(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt, sdrtrk_t *trk, int snrflag)
+{
+    obs_age_d(trk->tow); obs_age_d(trk->L); obs_age_d(trk->D);
+    obs_age_u(trk->codei); obs_age_u(trk->cntout); obs_age_d(trk->remcout);
+    trk->tow[0] = sdr->nav.firstsftow + (double)(cnt - sdr->nav.firstsfcnt) * sdr->ctime;
+    trk->codei[0] = buffloc;
+    trk->cntout[0] = cnt;
+    trk->remcout[0] = trk->oldremcode * sdr->f_sf / trk->codefreq;
+    trk->D[0] = -(trk->carrfreq - sdr->f_if - sdr->foffset);                /* Doppler */
+    if (!trk->flagremcarradd) {                                             /* carrier phase: the start phase, once */
+        trk->L[0] -= trk->remcarr / DPI;
+        trk->flagremcarradd = ON;
+    }
+    if (sdr->nav.flagsyncf && !trk->flagpolarityadd) {                      /* half a cycle for an inverted frame, once */
+        if (sdr->nav.polarity == 1) trk->L[0] += 0.5;
+        trk->flagpolarityadd = ON;
+    }
+    trk->L[0] += trk->D[0] * (trk->loopms * sdr->currnsamp / sdr->f_sf);
+    trk->Isum += fabs(trk->sumI[0]);
+    if (snrflag) {
+        obs_age_d(trk->S); obs_age_u(trk->codeisum);
+        trk->S[0] = 10 * log(trk->Isum / 100.0 / 100.0) + log(500.0) + 5;
+        trk->codeisum[0] = buffloc;
+        trk->Isum = 0;
+    }
+}
+
+/* setobsdata() over the log of a device-resident closed-loop run (include/gnsscorr.h): the same statements in the
+ * same order on the same doubles, fed from the log rows instead of sdrtrk_t */
+int gnsscorr_obs_replay(gnsscorr_obs_t *st, const gnsscorr_trklog_t *rows, const double *II0, int nper, uint64_t cnt0,
+                        gnsscorr_obsrow_t *out, int max_out)
+{
+    if (!st || !rows || !II0 || nper < 0 || (max_out > 0 && !out) || st->loopms < 1) return GNSSCORR_EINVAL;
+    int nout = 0;
+    for (int p = 0; p < nper; p++) {
+        const gnsscorr_trklog_t *r = rows + p;
+        const uint64_t cnt = cnt0 + (uint64_t)p;
+        st->sumI0 += II0[p];                                                /* cumsumcorr(): sumI += II (polarity +1) */
+        if (r->flagloopfilter == 2) {                                       /* ref src/sdrmain.c:277-288 */
+            const int snrflag = st->loopcnt % (uint64_t)(100 / st->loopms) == 0;        /* SNSMOOTHMS = 100, ref src/sdr.h:198 */
+            gnsscorr_obsrow_t o;
+            memset(&o, 0, sizeof(o));
+            o.tow = st->firstsftow + (double)(cnt - st->firstsfcnt) * st->ctime;
+            o.codei = r->buffloc;
+            o.cntout = cnt;
+            o.remcout = st->oldremcode * st->f_sf / r->codefreq;
+            o.D = -(r->carrfreq - st->f_if - st->foffset);
+            if (!st->flagremcarradd) {
+                st->L -= r->remcarr / DPI;
+                st->flagremcarradd = 1;
+            }
+            if (st->flagsyncf && !st->flagpolarityadd) {
+                if (st->polarity == 1) st->L += 0.5;
+                st->flagpolarityadd = 1;
+            }
+            st->L += o.D * (st->loopms * r->currnsamp / st->f_sf);
+            o.L = st->L;
+            st->Isum += fabs(st->sumI0);
+            if (snrflag) {
+                o.S = 10 * log(st->Isum / 100.0 / 100.0) + log(500.0) + 5;
+                o.snr = 1;
+                st->Isum = 0;
+            }
+            st->loopcnt++;
+            if (nout < max_out) out[nout] = o;
+            nout++;
+        }
+        if (r->flagloopfilter) st->sumI0 = 0.0;                             /* clearcumsumcorr() */
+        st->oldremcode = r->remcode;                                        /* the next period's oldremcode */
+    }
+    return nout;
+}
+
 /* 2nd order PLL assisted by a 1st order FLL */
 void pll(sdrch_t *sdr, sdrtrkprm_t *prm, double dt)
 {

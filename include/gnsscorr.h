@@ -209,6 +209,38 @@ typedef struct {
     int    navbit;                          /* +-1: checkbit() decided a bit in this period (swsync), else 0 */
 } gnsscorr_trklog_t;
 
+/* Observables on the batched outputs: setobsdata() (ref src/sdrtrk.c:160-209) replayed over the log of a closed-loop
+ * run.  The reference calls it from sdrthread() after every prm2 filter update (ref src/sdrmain.c:279-288) with
+ * snrflag every SNSMOOTHMS = 100 ms; everything it reads is in the log row of that period, the row before it
+ * (oldremcode) and the prompt sums of the interval (sumI[0] before clearcumsumcorr).  Plain host code, no device.
+ * State carried from call to call (a channel's log may be replayed in pieces): */
+typedef struct {
+    /* constants of the channel: ref sdrch_t.f_sf / .f_if / .foffset / .ctime, sdrtrk_t.loopms */
+    double f_sf, f_if, foffset, ctime;
+    int    loopms;
+    /* from the frame decoder (ref sdrnav_t.flagsyncf / .polarity / .firstsftow / .firstsfcnt); zero until it sets them */
+    int    flagsyncf, polarity;
+    double firstsftow;
+    uint64_t firstsfcnt;
+    /* running state: ref sdrtrk_t.L[0] / .Isum / .flagremcarradd / .flagpolarityadd, sdrthread's loopcnt, the
+     * interval's sumI[0] so far, the remcode of the period before the next one (sdrtrk_t.oldremcode) */
+    double L, Isum, sumI0, oldremcode;
+    int    flagremcarradd, flagpolarityadd;
+    uint64_t loopcnt;
+} gnsscorr_obs_t;
+/* one row per call of setobsdata(): element [0] of sdrtrk_t.tow / codei / cntout / remcout / L / D after it,
+ * and S / codeisum when the call computed them (snr != 0) */
+typedef struct {
+    double tow, remcout, L, D, S;
+    uint64_t codei, cntout;
+    int    snr, pad;
+} gnsscorr_obsrow_t;
+/* log[nper]: rows of one channel (gnsscorr_trk_fetch_log); II0[nper]: that channel's sdrtrk_t.II[0] per period
+ * (gnsscorr_trk_fetch's II, tap 0); cnt0: sdrthread's cnt at log[0].  Writes at most max_out rows, returns their
+ * number (or GNSSCORR_EINVAL). */
+int  gnsscorr_obs_replay(gnsscorr_obs_t *st, const gnsscorr_trklog_t *log, const double *II0, int nper, uint64_t cnt0,
+                         gnsscorr_obsrow_t *out, int max_out);
+
 /* Track `nperiod` code periods of every channel closed loop.  A channel stops early
  * where sdrtracking() would find no data yet (ref src/sdrtrk.c:26-30: bufflocnow
  * <= buffloc).  Returns when the last launches are queued (it keeps at most a few

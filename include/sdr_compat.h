@@ -224,6 +224,7 @@ extern uint64_t sdracquisition(sdrch_t *sdr, double *power);
 extern int checkacquisition(double *P, sdrch_t *sdr);
 extern uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt);
 extern void cumsumcorr(sdrtrk_t *trk, int polarity);
+extern void setobsdata(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt, sdrtrk_t *trk, int snrflag);      /* ref src/sdr.h: setobsdata, src/sdrtrk.c:160-209 */
 extern void clearcumsumcorr(sdrtrk_t *trk);
 extern void pll(sdrch_t *sdr, sdrtrkprm_t *prm, double dt);
 extern void dll(sdrch_t *sdr, sdrtrkprm_t *prm, double dt);

@@ -763,11 +763,42 @@ int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc
         orc_pll(ch, 1, (double)ch->loopms / 1000);
         orc_dll(ch, 1, (double)ch->loopms / 1000);
         ch->flagloopfilter = 2;
+        /* ref src/sdrmain.c:283-288: SNSMOOTHMS = 100 (src/sdr.h:198) */
+        orc_setobsdata(ch, *buffloc, ch->cnt, ch->loopcnt % (uint64_t)(100 / ch->loopms) == 0 ? 1 : 0);
+        ch->loopcnt++;
     }
     if (ch->flagloopfilter) orc_clearcumsumcorr(ch);
     ch->cnt++;
     *buffloc += (uint64_t)ch->currnsamp;
     return 1;
+}
+
+/* ref src/sdrtrk.c:160-209 */
+void orc_setobsdata(orc_chan_t *ch, uint64_t buffloc, uint64_t cnt, int snrflag)
+{
+    const double dpi = 2.0 * 3.1415926535897932;                     /* DPI, ref src/sdr.h:103-104 */
+    ch->obs_tow = ch->firstsftow + (double)(cnt - ch->firstsfcnt) * ch->ctime;       /* :170-171 */
+    ch->obs_codei = buffloc;
+    ch->obs_cntout = cnt;
+    ch->obs_remcout = ch->oldremcode * ch->f_sf / ch->codefreq;     /* :174 */
+    ch->obs_D = -(ch->carrfreq - ch->f_if - ch->foffset);           /* :177 */
+    if (!ch->flagremcarradd) {                                      /* :180-184 */
+        ch->obs_L -= ch->remcarr / dpi;
+        ch->flagremcarradd = 1;
+    }
+    if (ch->flagsyncf && !ch->flagpolarityadd) {                    /* :186-194 */
+        if (ch->polarity == 1) ch->obs_L += 0.5;
+        ch->flagpolarityadd = 1;
+    }
+    ch->obs_L += ch->obs_D * (ch->loopms * ch->currnsamp / ch->f_sf);       /* :196 */
+    ch->obs_Isum += fabs(ch->sumI[0]);                              /* :198 */
+    if (snrflag) {                                                  /* :199-208 */
+        ch->obs_S = 10 * log(ch->obs_Isum / 100.0 / 100.0) + log(500.0) + 5;
+        ch->obs_codeisum = buffloc;
+        ch->obs_Isum = 0;
+        ch->obs_nsnr++;
+    }
+    ch->obs_n++;
 }
 
 /* ref src/rcv/stereo/stereo.c:160-205 */

@@ -137,6 +137,12 @@ typedef struct {
     int    biti, bit, swsync, swreset, flagpol;
     double bitIP;
     int    bitsync[20];     /* sdrnav_t.bitsync[rate] */
+    /* observables (ref sdrtrk_t tow/codei/cntout/remcout/L/D/S [0], Isum, the two once-only flags; src/sdr.h:384-411)
+     * and what the frame decoder hands setobsdata() (ref sdrnav_t firstsftow/firstsfcnt/flagsyncf/polarity) */
+    double obs_tow, obs_remcout, obs_L, obs_D, obs_S, obs_Isum;
+    uint64_t obs_codei, obs_cntout, obs_codeisum, firstsfcnt, loopcnt;
+    double firstsftow;
+    int    flagremcarradd, flagpolarityadd, flagsyncf, polarity, obs_n, obs_nsnr;
 } orc_chan_t;
 
 /* ref src/sdrinit.c:583-657 (+ :385-394, :402-480); xcode left NULL */
@@ -165,6 +171,9 @@ void orc_dll(orc_chan_t *ch, int prm, double dt);
  * ch->flagsync/synci), cumsumcorr, pll/dll per the flagsync/swloop cadence, clearcumsumcorr, cnt++,
  * *buffloc += currnsamp.  Returns ch->flagtrk. */
 int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc);
+/* ref src/sdrtrk.c:160-209: element [0] of the observable histories after the call (the reference shifts the
+ * histories down by one first; element [0] keeps its value across the shift: L accumulates) */
+void orc_setobsdata(orc_chan_t *ch, uint64_t buffloc, uint64_t cnt, int snrflag);
 
 /* front-end sample expansion: ref src/rcv/stereo/stereo.c:160-205 (dtype 1: front end 1 from bits 7-6,
  * dtype 2: front end 2 I/Q from bits 5-3 / 2-0) and src/rcv/rtlsdr/rtlsdr.c:136-143 */

@@ -38,7 +38,11 @@ class Chan(C.Structure):
                 [(n, C.c_int) for n in ("rate", "flagsync", "synci", "navcnt", "swloop", "flagloopfilter")] +
                 [("cnt", C.c_uint64)] +
                 [(n, C.c_int) for n in ("prn", "biti", "bit", "swsync", "swreset", "flagpol")] +
-                [("bitIP", C.c_double), ("bitsync", C.c_int * 20)])
+                [("bitIP", C.c_double), ("bitsync", C.c_int * 20)] +
+                [(n, C.c_double) for n in ("obs_tow", "obs_remcout", "obs_L", "obs_D", "obs_S", "obs_Isum")] +
+                [(n, C.c_uint64) for n in ("obs_codei", "obs_cntout", "obs_codeisum", "firstsfcnt", "loopcnt")] +
+                [("firstsftow", C.c_double)] +
+                [(n, C.c_int) for n in ("flagremcarradd", "flagpolarityadd", "flagsyncf", "polarity", "obs_n", "obs_nsnr")])
 
 
 _lib = None
@@ -87,6 +91,8 @@ def lib():
     L.orc_pll.argtypes = [C.POINTER(Chan), i, d]
     L.orc_dll.argtypes = [C.POINTER(Chan), i, d]
     L.orc_sdrthread_step.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.POINTER(C.c_uint64)]
+    L.orc_setobsdata.argtypes = [C.POINTER(Chan), C.c_uint64, C.c_uint64, i]
+    L.orc_setobsdata.restype = None
     L.orc_stereo_exp.argtypes = [vp, i, i, vp]
     L.orc_rtlsdr_exp.argtypes = [vp, i, vp]
     _lib = L

@@ -70,6 +70,14 @@ def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, fl
         loops.append(engine.loop_state(i, acqfreq, flagsync=flagsync, synci=o.synci, cnt=o.cnt))
     engine.trk_set_state(states)
     engine.loop_set(loops)
+    # the observables (setobsdata, ref src/sdrtrk.c:160-209): replayed over the device's log, against the oracle's calls
+    # inside its loop
+    obs = []
+    for o in ochs:
+        st = gc.ObsState()
+        st.f_sf, st.f_if, st.foffset, st.ctime, st.loopms = o.f_sf, o.f_if, o.foffset, o.ctime, o.loopms
+        st.oldremcode = o.remcode
+        obs.append(st)
     done = 0
     for nrun in chunks:                                         # several runs: the state must carry over
         engine.trk_run_loop(nrun)
@@ -77,8 +85,12 @@ def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, fl
         log, ndone = engine.trk_fetch_log()
         assert np.all(ndone == nrun)
         for i, o in enumerate(ochs):
+            cnt0, want = o.cnt, []
             for e in range(nrun):
+                nobs = o.obs_n
                 assert L.orc_sdrthread_step(C.byref(o), C.byref(ring), C.byref(bufflocs[i])) == 1
+                if o.obs_n != nobs:
+                    want.append((o.obs_tow, o.obs_remcout, o.obs_L, o.obs_D, o.obs_S, o.obs_Isum == 0.0, o.obs_codei, o.obs_cntout))
                 ntap = 1 + 2 * corrn
                 where = (i, done + e)
                 assert ns[i, e] == o.currnsamp, where
@@ -89,6 +101,13 @@ def _run_case(gc, orc, synth, engine, dtype, f_if, corrn, corrd, corrp, nper, fl
                 assert r["flagloopfilter"] == o.flagloopfilter, where
                 assert r["remcode"] == o.remcode and r["remcarr"] == o.remcarr, where
                 _adopt(o, r, where)
+            rows = gc.obs_replay(obs[i], log[i], II[i, :, 0], cnt0=cnt0)
+            assert len(rows) == len(want), (i, len(rows), len(want))
+            for r, w in zip(rows, want):
+                # (Doppler and what follows from it inherit the ulp of the filters' atan: _adopt)
+                assert r["tow"] == w[0] and int(r["codei"]) == w[6] and int(r["cntout"]) == w[7], (i, w)
+                assert _close(r["remcout"], w[1]) and _close(r["L"], w[2], 1e-12) and _close(r["D"], w[3]), (i, w)
+                assert bool(r["snr"]) == w[5] and (not w[5] or _close(r["S"], w[4], 1e-12)), (i, w)
         done += nrun
     fin = engine.trk_get_state()
     lst = engine.loop_get()

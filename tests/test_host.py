@@ -135,3 +135,90 @@ def test_loop_filters_product_vs_oracle(gc, orc):
             L.clearcumsumcorr(C.byref(sdr.trk))
             orc.lib().orc_clearcumsumcorr(C.byref(o))
     L.freesdrch(C.byref(sdr))
+
+
+def test_setobsdata_product_vs_oracle(gc, orc):
+    """setobsdata() (ref src/sdrtrk.c:160-209) on the reference's sdrch_t against the oracle's restatement, 250 calls
+    with random loop outputs: Doppler, accumulated carrier phase, remaining code phase, the SNR of every 10th call, and
+    the histories moving down by one."""
+    L = gc.lib()
+    sdr = gc.SdrCh()
+    assert L.initsdrch(1, gc.SYS_GPS, 1, gc.CTYPE_L1CA, 2, 1, 1575.42e6, 16.368e6, 0.0, C.byref(sdr)) == 0
+    o = orc.make_chan(1, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+    L.setobsdata.argtypes = [C.POINTER(gc.SdrCh), C.c_uint64, C.c_uint64, C.POINTER(gc.SdrTrk), C.c_int]
+    L.setobsdata.restype = None
+    rng = np.random.default_rng(77)
+    buffloc, prevL = 1000, 0.0
+    for k in range(250):
+        cf, df = 1400.0 + rng.uniform(-30, 30), o.crate + rng.uniform(-2, 2)
+        rc, rp, n, si = rng.uniform(0, 1), rng.uniform(-50, 6.2), int(rng.integers(16366, 16371)), rng.uniform(-5e4, 5e4)
+        sdr.trk.carrfreq = o.carrfreq = cf
+        sdr.trk.codefreq = o.codefreq = df
+        sdr.trk.oldremcode = o.oldremcode = rc
+        sdr.trk.remcarr = o.remcarr = rp
+        sdr.currnsamp = o.currnsamp = n
+        sdr.trk.sumI[0] = o.sumI[0] = si
+        snr = 1 if k % 10 == 0 else 0
+        L.setobsdata(C.byref(sdr), buffloc, 2001 + 10 * k, C.byref(sdr.trk), snr)
+        orc.lib().orc_setobsdata(C.byref(o), buffloc, 2001 + 10 * k, snr)
+        assert sdr.trk.L[0] == o.obs_L and sdr.trk.D[0] == o.obs_D and sdr.trk.remcout[0] == o.obs_remcout
+        assert sdr.trk.tow[0] == o.obs_tow and sdr.trk.codei[0] == o.obs_codei and sdr.trk.cntout[0] == o.obs_cntout
+        assert sdr.trk.Isum == o.obs_Isum and sdr.trk.S[0] == o.obs_S
+        if k:
+            assert sdr.trk.L[1] == prevL and sdr.trk.cntout[1] == 2001 + 10 * (k - 1)
+        prevL = sdr.trk.L[0]
+        buffloc += 10 * n
+    assert sdr.trk.flagremcarradd == 1 and o.obs_nsnr == 25
+    L.freesdrch(C.byref(sdr))
+
+
+def test_observables_replayed_over_a_loop_log(gc, orc, synth):
+    """gnsscorr_obs_replay: setobsdata() over the per-period log of a closed-loop run equals setobsdata() called inside
+    the loop where the reference calls it (ref src/sdrmain.c:277-288; here the oracle's thread loop on a synthetic
+    signal, nav bit synchronised, an inverted frame reported half way) -- bit for bit, in one piece and in two."""
+    NS, NP = 16368, 420
+    rng = np.random.default_rng(5)
+    data = rng.integers(-40, 41, size=((NP + 4) * NS, 2), dtype=np.int8)
+    ring = orc.make_ring(data, data.shape[0], data.shape[0])
+    o = orc.make_chan(3, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3)
+    o.acq.acqfreq = o.carrfreq = 1200.0
+    o.codefreq = o.crate
+    o.remcode, o.remcarr = 0.25, 1.5
+    o.flagacq = 1
+    o.flagsync, o.synci, o.cnt, o.prn = 1, 7, 2001, 3
+    st = gc.ObsState()
+    st.f_sf, st.f_if, st.foffset, st.ctime, st.loopms = o.f_sf, o.f_if, o.foffset, o.ctime, o.loopms
+    st.oldremcode = o.remcode
+    st.firstsftow, st.firstsfcnt = 345600.0, 1500
+    o.firstsftow, o.firstsfcnt = 345600.0, 1500
+    log = np.zeros(NP, dtype=np.dtype(gc.TrkLog))
+    II0 = np.zeros(NP)
+    want = []
+    buffloc = C.c_uint64(11)
+    for p in range(NP):
+        if p == NP // 2:            # the frame decoder has found an inverted preamble
+            o.flagsyncf, o.polarity = 1, 1
+        n_before = o.obs_n
+        b0 = buffloc.value
+        assert orc.lib().orc_sdrthread_step(C.byref(o), C.byref(ring), C.byref(buffloc)) == 1
+        log[p]["carrfreq"], log[p]["codefreq"] = o.carrfreq, o.codefreq
+        log[p]["remcode"], log[p]["remcarr"] = o.remcode, o.remcarr
+        log[p]["buffloc"], log[p]["currnsamp"], log[p]["flagloopfilter"] = b0, o.currnsamp, o.flagloopfilter
+        II0[p] = o.II[0]
+        if o.obs_n != n_before:
+            want.append((o.obs_tow, o.obs_remcout, o.obs_L, o.obs_D, o.obs_S if o.obs_Isum == 0.0 else None, o.obs_codei,
+                         o.obs_cntout))
+    assert len(want) >= 40
+    # in two pieces, the frame decoder's report handed over between them
+    half = NP // 2
+    rows = list(gc.obs_replay(st, log[:half], II0[:half], cnt0=2001))
+    st.flagsyncf, st.polarity = 1, 1
+    rows += list(gc.obs_replay(st, log[half:], II0[half:], cnt0=2001 + half))
+    assert len(rows) == len(want)
+    for r, w in zip(rows, want):
+        assert (r["tow"], r["remcout"], r["L"], r["D"], int(r["codei"]), int(r["cntout"])) == (w[0], w[1], w[2], w[3], w[5], w[6])
+        if w[4] is not None:
+            assert r["snr"] == 1 and r["S"] == w[4]
+        else:
+            assert r["snr"] == 0
+    assert any(r["snr"] for r in rows) and st.flagpolarityadd == 1
