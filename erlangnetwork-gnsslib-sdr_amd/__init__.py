@@ -101,6 +101,24 @@ def obs_replay(state, log_rows, II0, cnt0=0):
     return out[:k]
 
 
+class FrameState(C.Structure):
+    """gnsscorr_frame_t: frame synchronisation of L1 C/A on the decided nav bits (ref src/sdrnav.c:41-82)."""
+    _fields_ = ([("fbits", C.c_int * 302)] + [(n, C.c_int) for n in ("polarity", "flagsyncf", "flagtow", "flagdec", "sfid", "pad")] +
+                [("firstsf", C.c_uint64), ("firstsfcnt", C.c_uint64), ("firstsftow", C.c_double), ("tow_gpst", C.c_double)])
+
+
+def frame_replay(state, log_rows, cnt0=0):
+    """The nav bits of one channel's log rows through the preamble search / parity check / hand-over word; `state`
+    (FrameState) is updated.  Host code only."""
+    L = lib()
+    L.gnsscorr_frame_replay.restype = C.c_int
+    L.gnsscorr_frame_replay.argtypes = [C.POINTER(FrameState), C.c_void_p, C.c_int, C.c_uint64]
+    log_rows = np.ascontiguousarray(log_rows)
+    rc = L.gnsscorr_frame_replay(C.byref(state), log_rows.ctypes.data, int(log_rows.shape[0]), int(cnt0))
+    if rc:
+        raise RuntimeError("gnsscorr_frame_replay: error %d" % rc)
+
+
 class AcqRes(C.Structure):
     _fields_ = [("acqcodei", C.c_int), ("freqi", C.c_int), ("acqfreq", C.c_double),
                 ("cn0", C.c_double), ("peakr", C.c_double), ("flagacq", C.c_int),

@@ -551,6 +551,93 @@ int gnsscorr_obs_replay(gnsscorr_obs_t *st, const gnsscorr_trklog_t *rows, const
     return nout;
 }
 
+/* ------------------------------------------------------------------------- */
+/* frame synchronisation of L1 C/A on the decided bits: ref src/sdrnav.c:41-82 */
+/* ------------------------------------------------------------------------- */
+/* One (32,26) word in the reference's +-1 arithmetic (ref src/sdrnav_gps.c:141-164): w[0], w[1] are the last two
+ * bits of the word before, w[2..25] the data bits as sent or complemented back, w[26..31] the parity bits.  Each
+ * parity bit is the product of the bits its row of the code names. */
+static int l1ca_word_ok(const int *w)
+{
+    static const signed char rows[6][17] = {
+        {0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24, -1},
+        {1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25, -1},
+        {0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23, -1},
+        {1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24, -1},
+        {1, 2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25, -1},
+        {0, 4, 6, 7, 9, 10, 11, 12, 14, 16, 20, 23, 24, 25, -1}};
+    int stat = 0;
+    for (int r = 0; r < 6; r++) {
+        int prod = 1;
+        for (int k = 0; rows[r][k] >= 0; k++) prod *= w[rows[r][k]];
+        stat += prod - w[26 + r];               /* (summed, as the reference does: not a per-bit comparison) */
+    }
+    return stat == 0;
+}
+
+/* the ten words of the frame in `raw` under the polarity the preamble gave (ref src/sdrnav.c:325-346) */
+static int l1ca_frame_parity(const int *raw, int polarity)
+{
+    int b[302], good = 0;
+    for (int i = 0; i < 302; i++) b[i] = polarity * raw[i];
+    for (int wd = 0; wd < 10; wd++) {
+        int *w = b + 30 * wd;
+        if (w[1] == -1)
+            for (int j = 2; j < 26; j++) w[j] = -w[j];
+        good += l1ca_word_ok(w);
+    }
+    return good == 10;
+}
+
+int gnsscorr_frame_replay(gnsscorr_frame_t *st, const gnsscorr_trklog_t *rows, int nper, uint64_t cnt0)
+{
+    static const int preamble[8] = {1, -1, -1, -1, 1, -1, 1, 1};           /* ref src/sdrinit.c:492 */
+    if (!st || !rows || nper < 0) return GNSSCORR_EINVAL;
+    for (int p = 0; p < nper; p++) {
+        const int bit = rows[p].navbit;
+        if (!bit) continue;                     /* checkbit() decided no bit in this period: swsync is off */
+        const uint64_t cnt = cnt0 + (uint64_t)p;
+        memmove(st->fbits, st->fbits + 1, sizeof(int) * 301);
+        st->fbits[301] = bit;
+        if (!st->flagtow) {                     /* preamble search (no FEC on this signal: the bits as they are) */
+            int corr = 0;
+            for (int i = 0; i < 8; i++) corr += st->fbits[2 + i] * preamble[i];
+            st->flagsyncf = 0;
+            if (corr == 8 || corr == -8) {
+                st->polarity = corr > 0 ? 1 : -1;
+                st->flagsyncf = l1ca_frame_parity(st->fbits, st->polarity);
+            }
+            if (st->flagsyncf) {
+                st->firstsf = rows[p].buffloc;
+                st->firstsfcnt = cnt;
+                st->flagtow = 1;
+            }
+        }
+        if (st->flagtow && (int)(cnt - st->firstsfcnt) % 6000 == 0) {      /* a whole subframe: 300 bits x 20 periods */
+            /* decode_l1ca(): data bits complemented back where the word before ended in a one (-1), then packed with
+             * -1 as one (ref src/sdrnav.c:154-171); subframe number = bits 49..51, time of week = bits 30..46 x 6 s */
+            int d[302];
+            memcpy(d, st->fbits, sizeof(d));
+            for (int wd = 0; wd < 10; wd++)
+                if (d[30 * wd + 1] == -1)
+                    for (int j = 2; j < 26; j++) d[30 * wd + j] = -d[30 * wd + j];
+            unsigned id = 0, tow = 0;
+            for (int i = 0; i < 3; i++) id = id * 2 + (d[2 + 49 + i] < 0);
+            for (int i = 0; i < 17; i++) tow = tow * 2 + (d[2 + 30 + i] < 0);
+            st->sfid = (int)id;
+            if (id >= 1 && id <= 5) st->tow_gpst = tow * 6.0;
+            if (st->tow_gpst == 0) {            /* no time of week: start over (ref src/sdrnav.c:68-71) */
+                st->flagsyncf = 0;
+                st->flagtow = 0;
+            } else if (cnt == st->firstsfcnt) {
+                st->flagdec = 1;
+                st->firstsftow = st->tow_gpst;
+            }
+        }
+    }
+    return GNSSCORR_OK;
+}
+
 /* 2nd order PLL assisted by a 1st order FLL */
 void pll(sdrch_t *sdr, sdrtrkprm_t *prm, double dt)
 {

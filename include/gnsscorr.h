@@ -241,6 +241,23 @@ typedef struct {
 int  gnsscorr_obs_replay(gnsscorr_obs_t *st, const gnsscorr_trklog_t *log, const double *II0, int nper, uint64_t cnt0,
                          gnsscorr_obsrow_t *out, int max_out);
 
+/* Frame synchronisation on the batched nav bits (GPS / QZSS L1 C/A): what sdrnavigation() does behind checkbit()
+ * (ref src/sdrnav.c:41-82) -- the last 302 decided bits, the preamble search with its parity check over the ten words
+ * (ref :373-411, :325-346, src/sdrnav_gps.c:141-164), and of the subframe decoder the subframe number and the time of
+ * week in the hand-over word (ref src/sdrnav_gps.c:123-135,170-190) -- replayed over the `navbit` column of a
+ * closed-loop log.  It yields what setobsdata() needs from the frame decoder: flagsyncf, polarity, firstsfcnt,
+ * firstsftow.  Ephemeris decoding is not part of this library.  Plain host code. */
+typedef struct {
+    int    fbits[302];                      /* ref sdrnav_t.fbits (flen 300 + addflen 2), newest last     */
+    int    polarity, flagsyncf, flagtow, flagdec;   /* ref sdrnav_t                                        */
+    int    sfid;                            /* subframe number decoded last (1..5; other: not a subframe) */
+    int    pad;
+    uint64_t firstsf, firstsfcnt;           /* ref sdrnav_t: sample / period counter of the frame's end   */
+    double firstsftow, tow_gpst;            /* ref sdrnav_t.firstsftow, sdreph_t.tow_gpst                 */
+} gnsscorr_frame_t;
+/* log[nper]: one channel's rows; cnt0: sdrthread's cnt at log[0].  Returns 0, or GNSSCORR_EINVAL. */
+int  gnsscorr_frame_replay(gnsscorr_frame_t *st, const gnsscorr_trklog_t *log, int nper, uint64_t cnt0);
+
 /* Track `nperiod` code periods of every channel closed loop.  A channel stops early
  * where sdrtracking() would find no data yet (ref src/sdrtrk.c:26-30: bufflocnow
  * <= buffloc).  Returns when the last launches are queued (it keeps at most a few

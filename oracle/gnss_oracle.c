@@ -773,6 +773,96 @@ int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc
     return 1;
 }
 
+/* ref src/sdrnav_gps.c:141-164 */
+static int orc_paritycheck_l1ca(const int *bits)
+{
+    int i, stat = 0, pbits[6];
+    pbits[0] = bits[0] * bits[2] * bits[3] * bits[4] * bits[6] * bits[7] * bits[11] * bits[12] *
+        bits[13] * bits[14] * bits[15] * bits[18] * bits[19] * bits[21] * bits[24];
+    pbits[1] = bits[1] * bits[3] * bits[4] * bits[5] * bits[7] * bits[8] * bits[12] * bits[13] *
+        bits[14] * bits[15] * bits[16] * bits[19] * bits[20] * bits[22] * bits[25];
+    pbits[2] = bits[0] * bits[2] * bits[4] * bits[5] * bits[6] * bits[8] * bits[9] * bits[13] *
+        bits[14] * bits[15] * bits[16] * bits[17] * bits[20] * bits[21] * bits[23];
+    pbits[3] = bits[1] * bits[3] * bits[5] * bits[6] * bits[7] * bits[9] * bits[10] * bits[14] *
+        bits[15] * bits[16] * bits[17] * bits[18] * bits[21] * bits[22] * bits[24];
+    pbits[4] = bits[1] * bits[2] * bits[4] * bits[6] * bits[7] * bits[8] * bits[10] * bits[11] *
+        bits[15] * bits[16] * bits[17] * bits[18] * bits[19] * bits[22] * bits[23] * bits[25];
+    pbits[5] = bits[0] * bits[4] * bits[6] * bits[7] * bits[9] * bits[10] * bits[11] * bits[12] *
+        bits[14] * bits[16] * bits[20] * bits[23] * bits[24] * bits[25];
+    for (i = 0; i < 6; i++) stat += (pbits[i] - bits[26 + i]);
+    return stat == 0;
+}
+
+/* ref src/sdrnav.c:325-346 (L1CA branch) */
+static int orc_paritycheck(const orc_frame_t *f)
+{
+    int i, j, stat = 0, bits[302];
+    for (i = 0; i < 302; i++) bits[i] = f->polarity * f->fbitsdec[i];
+    for (i = 0; i < 10; i++) {
+        if (bits[i * 30 + 1] == -1)
+            for (j = 2; j < 26; j++) bits[i * 30 + j] *= -1;
+        stat += orc_paritycheck_l1ca(&bits[i * 30]);
+    }
+    return stat == 10;
+}
+
+/* ref src/sdrnav.c:373-411 (L1CA branch); pre_l1ca: src/sdrinit.c:492 */
+static int orc_findpreamble(orc_frame_t *f)
+{
+    static const int pre[8] = {1, -1, -1, -1, 1, -1, 1, 1};
+    int i, corr = 0;
+    for (i = 0; i < 8; i++) corr += f->fbitsdec[2 + i] * pre[i];
+    if (abs(corr) == 8) {
+        f->polarity = corr > 0 ? 1 : -1;
+        if (orc_paritycheck(f)) return 1;
+    }
+    return 0;
+}
+
+/* ref src/sdrnav_gps.c:170-190, :123-135, :18 (tow) with bits2byte (src/sdrnav.c:154-171: -1 => 1) and RTKLIB's
+ * getbitu (most significant bit first) */
+static int orc_decode_l1ca(orc_frame_t *f)
+{
+    int i, j, id = 0;
+    unsigned tow = 0;
+    for (i = 0; i < 10; i++)
+        if (f->fbitsdec[i * 30 + 1] == -1)
+            for (j = 2; j < 26; j++) f->fbitsdec[i * 30 + j] *= -1;
+    for (i = 0; i < 3; i++) id = (id << 1) | (f->fbitsdec[2 + 49 + i] < 0 ? 1 : 0);
+    for (i = 0; i < 17; i++) tow = (tow << 1) | (f->fbitsdec[2 + 30 + i] < 0 ? 1u : 0u);
+    if (id >= 1 && id <= 5) f->tow_gpst = tow * 6.0;      /* (decode_frame_l1ca decodes subframes 1..5 only) */
+    return id;
+}
+
+/* ref src/sdrnav.c:41-82 */
+void orc_navframe_l1ca(orc_frame_t *f, int bit, uint64_t buffloc, uint64_t cnt)
+{
+    int i;
+    if (!bit) return;                                   /* (swsync off: nothing behind checkbit() runs) */
+    for (i = 0; i + 1 < 302; i++) f->fbits[i] = f->fbits[i + 1];       /* checkbit(), ref :274-277 */
+    f->fbits[301] = bit;
+    if (!f->flagtow) memcpy(f->fbitsdec, f->fbits, sizeof(f->fbits));   /* predecodefec */
+    if (!f->flagtow) f->flagsyncf = orc_findpreamble(f);
+    if (f->flagsyncf && !f->flagtow) {
+        f->firstsf = buffloc;
+        f->firstsfcnt = cnt;
+        f->flagtow = 1;
+    }
+    if (f->flagtow) {
+        if ((int)(cnt - f->firstsfcnt) % 6000 == 0) {   /* nav->update = flen * rate = 300 * 20 */
+            memcpy(f->fbitsdec, f->fbits, sizeof(f->fbits));
+            f->sfid = orc_decode_l1ca(f);
+            if (f->tow_gpst == 0) {
+                f->flagsyncf = 0;
+                f->flagtow = 0;
+            } else if (cnt - f->firstsfcnt == 0) {
+                f->flagdec = 1;
+                f->firstsftow = f->tow_gpst;
+            }
+        }
+    }
+}
+
 /* ref src/sdrtrk.c:160-209 */
 void orc_setobsdata(orc_chan_t *ch, uint64_t buffloc, uint64_t cnt, int snrflag)
 {

@@ -171,6 +171,19 @@ void orc_dll(orc_chan_t *ch, int prm, double dt);
  * ch->flagsync/synci), cumsumcorr, pll/dll per the flagsync/swloop cadence, clearcumsumcorr, cnt++,
  * *buffloc += currnsamp.  Returns ch->flagtrk. */
 int orc_sdrthread_step(orc_chan_t *ch, const orc_ring_t *ring, uint64_t *buffloc);
+/* Frame synchronisation of GPS L1 C/A on the decided nav bits: the part of sdrnavigation() behind checkbit()
+ * (ref src/sdrnav.c:41-82) with predecodefec (:288-297: a copy for L1CA), findpreamble (:373-411), paritycheck
+ * (:325-346) + paritycheck_l1ca (src/sdrnav_gps.c:141-164) and, of decodenav, the subframe number and the time of
+ * week of the hand-over word (decode_l1ca :170-190, decode_frame_l1ca :123-135, tow_gpst = getbitu(buff,30,17)*6). */
+typedef struct {
+    int fbits[302], fbitsdec[302];          /* ref sdrnav_t.fbits / .fbitsdec, flen 300 + addflen 2 */
+    int polarity, flagsyncf, flagtow, flagdec, sfid;
+    uint64_t firstsf, firstsfcnt;
+    double firstsftow, tow_gpst;
+} orc_frame_t;
+/* bit: what checkbit() appended to fbits in this period (+-1), or 0 when it decided none (swsync off) */
+void orc_navframe_l1ca(orc_frame_t *f, int bit, uint64_t buffloc, uint64_t cnt);
+
 /* ref src/sdrtrk.c:160-209: element [0] of the observable histories after the call (the reference shifts the
  * histories down by one first; element [0] keeps its value across the shift: L accumulates) */
 void orc_setobsdata(orc_chan_t *ch, uint64_t buffloc, uint64_t cnt, int snrflag);

@@ -45,6 +45,12 @@ class Chan(C.Structure):
                 [(n, C.c_int) for n in ("flagremcarradd", "flagpolarityadd", "flagsyncf", "polarity", "obs_n", "obs_nsnr")])
 
 
+class Frame(C.Structure):
+    _fields_ = [("fbits", C.c_int * 302), ("fbitsdec", C.c_int * 302)] + [(n, C.c_int) for n in (
+        "polarity", "flagsyncf", "flagtow", "flagdec", "sfid")] + [("firstsf", C.c_uint64), ("firstsfcnt", C.c_uint64),
+        ("firstsftow", C.c_double), ("tow_gpst", C.c_double)]
+
+
 _lib = None
 
 
@@ -93,6 +99,8 @@ def lib():
     L.orc_sdrthread_step.argtypes = [C.POINTER(Chan), C.POINTER(Ring), C.POINTER(C.c_uint64)]
     L.orc_setobsdata.argtypes = [C.POINTER(Chan), C.c_uint64, C.c_uint64, i]
     L.orc_setobsdata.restype = None
+    L.orc_navframe_l1ca.argtypes = [C.POINTER(Frame), i, C.c_uint64, C.c_uint64]
+    L.orc_navframe_l1ca.restype = None
     L.orc_stereo_exp.argtypes = [vp, i, i, vp]
     L.orc_rtlsdr_exp.argtypes = [vp, i, vp]
     _lib = L

@@ -222,3 +222,81 @@ def test_observables_replayed_over_a_loop_log(gc, orc, synth):
         else:
             assert r["snr"] == 0
     assert any(r["snr"] for r in rows) and st.flagpolarityadd == 1
+
+
+_L1CA_ROWS = ((0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24), (1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25),
+              (0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23), (1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24),
+              (1, 2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25), (0, 4, 6, 7, 9, 10, 11, 12, 14, 16, 20, 23, 24, 25))
+
+
+def _l1ca_subframe(rng, prev2, tow_count, sfid, polarity):
+    """300 bits (+-1, as checkbit() would decide them) of one subframe that the reference's frame synchronisation
+    accepts (ref src/sdrnav.c:325-346,373-411; src/sdrnav_gps.c:141-164), built by running its checks backwards:
+    `b` is the frame as paritycheck() sees it after multiplying by the polarity; plain data bits, complemented for
+    sending where the word before ended in -1, six parity bits from the products.  prev2: the two bits in front."""
+    pre = [1, -1, -1, -1, 1, -1, 1, 1]
+    b = list(prev2)
+    for wd in range(10):
+        d29, d30 = b[-2], b[-1]
+        plain = [int(x) for x in rng.choice([-1, 1], size=24)]
+        if wd == 0:
+            plain[:8] = [v * (-1 if d30 == -1 else 1) for v in pre]          # so that the SENT bits are the preamble
+        if wd == 1:
+            # what decode_l1ca() will read: it works on the undecided-polarity bits r = polarity * b, complements them
+            # back where r's word before ended in -1, and packs -1 as one
+            want = [(tow_count >> (16 - i)) & 1 for i in range(17)] + [0, 0] + [(sfid >> (2 - i)) & 1 for i in range(3)]
+            for i, bit in enumerate(want):
+                r_after = -1 if bit else 1                                      # value after decode's complementing
+                r_sent = r_after * (-1 if polarity * d30 == -1 else 1)
+                b_sent = polarity * r_sent
+                plain[i] = b_sent * (-1 if d30 == -1 else 1)
+        w = [d29, d30] + plain
+        par = []
+        for row in _L1CA_ROWS:
+            prod = 1
+            for k in row:
+                prod *= w[k]
+            par.append(prod)
+        sent = [v * (-1 if d30 == -1 else 1) for v in plain] + par
+        b += sent
+    return [polarity * v for v in b[2:]], b[-2:]
+
+
+def test_frame_sync_on_batched_nav_bits(gc, orc):
+    """gnsscorr_frame_replay (preamble search, parity over the ten words, subframe number and time of week of the
+    hand-over word: ref src/sdrnav.c:41-82) against the oracle's restatement, bit by bit: random bits (no false lock
+    that the oracle does not share), then three consecutive subframes for either polarity of the bit stream."""
+    rng = np.random.default_rng(2024)
+    for polarity in (1, -1):
+        bits = [int(x) for x in rng.choice([-1, 1], size=777)]
+        prev2 = [polarity * bits[-2], polarity * bits[-1]]
+        tow0 = 34567
+        for k in range(3):
+            sf, prev2 = _l1ca_subframe(rng, prev2, tow0 + k, 1 + k, polarity)
+            bits += sf
+        bits += [int(x) for x in rng.choice([-1, 1], size=40)]
+        # one decided bit every 20 periods (rate 20), the first at period 7
+        nper = 7 + 20 * len(bits)
+        log = np.zeros(nper, dtype=np.dtype(gc.TrkLog))
+        for i, bv in enumerate(bits):
+            log[7 + 20 * i]["navbit"] = bv
+            log[7 + 20 * i]["buffloc"] = 1000 + 16368 * (7 + 20 * i)
+        of = orc.Frame()
+        st = gc.FrameState()
+        cnt0, done = 5000, 0
+        sync_at = None
+        for chunk in (1, 4000, 9000, nper - 13001):                 # in pieces: the state carries over
+            gc.frame_replay(st, log[done:done + chunk], cnt0=cnt0 + done)
+            for p in range(done, done + chunk):
+                orc.lib().orc_navframe_l1ca(C.byref(of), int(log[p]["navbit"]), int(log[p]["buffloc"]), cnt0 + p)
+                if of.flagtow and sync_at is None:
+                    sync_at = p
+            done += chunk
+            assert list(st.fbits) == list(of.fbits)
+            for f in ("polarity", "flagsyncf", "flagtow", "flagdec", "sfid", "firstsf", "firstsfcnt", "firstsftow", "tow_gpst"):
+                assert getattr(st, f) == getattr(of, f), (polarity, done, f)
+        # locked at the last bit of the first constructed subframe, and never lost
+        first_end = 7 + 20 * (777 + 300 - 1)
+        assert sync_at == first_end and st.flagtow == 1 and st.flagsyncf == 1 and st.firstsfcnt == cnt0 + first_end
+        assert st.firstsf == 1000 + 16368 * first_end
+        assert st.flagdec == 1 and st.firstsftow == tow0 * 6.0 and st.sfid == 3 and st.tow_gpst == (tow0 + 2) * 6.0
