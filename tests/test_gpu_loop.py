@@ -291,3 +291,63 @@ def test_closed_loop_bit_sync_on_the_device(gc, orc, synth, engine):
             assert getattr(lst[i], f) == getattr(o, f), (i, f)
         assert list(lst[i].bitsync) == list(o.bitsync), i
         assert abs(o.carrfreq - dop[i]) < 30.0, (i, o.carrfreq)       # ... and the loops stayed locked on it
+
+
+def test_acquisition_state_to_frame_and_observables(gc, orc, synth, engine):
+    """The whole thread loop of a channel on a signal that carries a navigation subframe (ref src/sdrmain.c:264-312,
+    src/sdrnav.c:15-84): from the state sdracquisition() leaves, the device runs the one-period loop, finds the bit
+    edge (checksync), switches to the ten-period loop and decides the bits (checkbit); the host then finds the frame
+    in the log's bits (gnsscorr_frame_replay: preamble, parity, hand-over word) and replays setobsdata()
+    (gnsscorr_obs_replay).  4.092 Msps, 8.6 s of signal, one satellite at +1234 Hz."""
+    from lnav_frames import l1ca_subframe
+    f_sf, nsamp, prn, dop, cph = 4.092e6, 4092, 7, 1234.0, 200.25
+    rng = np.random.default_rng(99)
+    lead = [int(x) for x in rng.choice([-1, 1], size=115)]
+    tow_count = 70001
+    sf, _ = l1ca_subframe(rng, [lead[-2], lead[-1]], tow_count, 2, 1)
+    bits = np.array(lead + sf + [int(x) for x in rng.choice([-1, 1], size=15)], np.float64)
+    nper = 8580
+    codes = {prn: gc.gencode(prn, gc.CTYPE_L1CA)}
+    sats = [dict(prn=prn, doppler=dop, codephase=cph, cn0=50.0, phase=0.7, bits=bits)]
+    sig = synth.make_if(codes, nsamp * (nper + 4), f_sf=f_sf, f_if=0.0, dtype=2, sats=sats, seed=7)
+    engine.ring_create(1, 2, sig.shape[0])
+    engine.ring_push_raw(1, sig, sig.shape[0])
+    ch = gc.Channel(prn, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=1, corrp=1)
+    assert ch.nsamp == nsamp
+    engine.set_channels([ch])
+    acqfreq = 200.0 * round(dop / 200.0)
+    b0 = int(round((1023 - cph) * 4)) % nsamp
+    engine.trk_set_state([dict(carrfreq=acqfreq, codefreq=ch.crate, remcode=0.0, remcarr=0.0, buffloc=b0)])
+    engine.loop_set([engine.loop_state(0, acqfreq, flagsync=0, synci=0, cnt=0)])
+    engine.trk_run_loop(nper)
+    II, QQ, ns = engine.trk_fetch()
+    log, ndone = engine.trk_fetch_log()
+    assert ndone[0] == nper
+    rows = log[0]
+    # bit synchronisation on the device: after period 2000, then the ten-period loop
+    first_sync = int(np.argmax(rows["flagsync"] != 0))
+    assert 2000 < first_sync < 2400 and np.all(rows["flagsync"][first_sync:] == 1)
+    assert np.all(rows["flagloopfilter"][:first_sync] == 1) and set(np.unique(rows["flagloopfilter"][first_sync + 20:])) == {0, 2}
+    decided = rows["navbit"][rows["navbit"] != 0]
+    assert len(decided) >= 300 + 5
+    # the frame in the decided bits
+    fr = gc.FrameState()
+    gc.frame_replay(fr, rows, cnt0=0)
+    end = (115 + 300) * 20                                      # the period in which the subframe's last bit ends
+    assert fr.flagtow == 1 and fr.flagsyncf == 1 and fr.flagdec == 1 and fr.polarity in (1, -1)
+    assert abs(int(fr.firstsfcnt) - end) <= 25 and fr.sfid == 2 and fr.firstsftow == tow_count * 6.0
+    assert fr.firstsf == int(rows["buffloc"][int(fr.firstsfcnt)])
+    # the observables, with what the frame decoder found
+    st = gc.ObsState()
+    st.f_sf, st.f_if, st.foffset, st.ctime, st.loopms = f_sf, 0.0, 0.0, 1e-3, 10
+    st.flagsyncf, st.polarity, st.firstsftow, st.firstsfcnt = fr.flagsyncf, fr.polarity, fr.firstsftow, fr.firstsfcnt
+    obs = gc.obs_replay(st, rows, II[0, :, 0], cnt0=0)
+    nupd = int((rows["flagloopfilter"] == 2).sum())
+    assert len(obs) == nupd and nupd > 550
+    assert np.all(np.abs(obs["D"][-200:] + dop) < 25.0)          # Doppler = -(carrfreq - f_if)
+    tail = obs[obs["cntout"] >= fr.firstsfcnt]                  # (before the frame's end the reference's tow is meaningless too)
+    assert len(tail) >= 20
+    assert np.allclose(np.diff(tail["tow"]), 0.01, atol=1e-9) and np.allclose(np.diff(tail["L"]), tail["D"][1:] * 0.01, rtol=1e-3)
+    k = int(np.argmax(obs["cntout"] >= fr.firstsfcnt))
+    assert abs(obs["tow"][k] - (tow_count * 6.0 + (int(obs["cntout"][k]) - int(fr.firstsfcnt)) * 1e-3)) < 1e-9
+    assert int(obs["snr"].sum()) == (nupd + 9) // 10 and np.all(obs["S"][obs["snr"] == 1][5:] > 30.0)
