@@ -388,7 +388,9 @@ def main():
     # ---- host-fed leg through the sharded driver (any N): rank 0 owns the IF stream in pinned HOST memory; every
     # batch's chunk is copied into rank 0's ring slot and broadcast from there into every rank's ring (RCCL), two chunks
     # ahead of the batch that reads it.  The PCIe- and xGMI-inclusive rate of the multi-GPU data path; never `value`.
-    if not os.environ.get("BENCH_NO_HOSTFED"):
+    # (at N > 1 only on request, BENCH_HOSTFED_SHARDED=1: it could not be rehearsed on RCCL with the one GPU at hand,
+    # and a leg that has never run must not stand between a scaling run and its JSON line)
+    if not os.environ.get("BENCH_NO_HOSTFED") and (world == 1 or os.environ.get("BENCH_HOSTFED_SHARDED")):
         log("host-fed leg through the sharded driver")
         chunk_host = torch.from_numpy(np.ascontiguousarray(data.reshape(-1))).pin_memory() if rank == 0 else None
         nl = 12
