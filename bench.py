@@ -385,6 +385,14 @@ def main():
                                   "trk_corr": k_ms / max(k_n, 1), "trk_finish": s_ms / max(s_n, 1)},
     }
 
+    # the same accounting over everything that produces the E/P/L sums of a launch on the main stream (the roofline
+    # line above is the dominant kernel alone; trk_edges and trk_expand prepare its look-ups and tables)
+    km = out["kernels_ms_per_launch"]
+    for name, ks in (("with_trk_edges", ("trk_edges", "trk_corr")), ("main_stream", ("trk_expand", "trk_edges", "trk_corr", "trk_finish"))):
+        ms = sum(km[k] for k in ks)
+        if ms > 0:
+            roof[name] = {"kernels": list(ks), "launch_ms": ms, "frac": NCH * E * bytes_unit / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
     # ---- host-fed leg through the sharded driver (any N): rank 0 owns the IF stream in pinned HOST memory; every
     # batch's chunk is copied into rank 0's ring slot and broadcast from there into every rank's ring (RCCL), two chunks
     # ahead of the batch that reads it.  The PCIe- and xGMI-inclusive rate of the multi-GPU data path; never `value`.
