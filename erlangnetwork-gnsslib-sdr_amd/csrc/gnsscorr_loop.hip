@@ -634,7 +634,9 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
             for (int i = 0; i < 13; i++) same = same && cc.dm[i] == __shfl(cc.dm[i], lane ^ 32, 64);
             const double other = __shfl(end, lane ^ 32, 64);
             if (!hiend) {
-                cc.tag = same ? 1 : 0;
+                // (the discovering step allows the widest tail; the chain's instance may be narrower)
+                const int tmax = c.smax + 1 > 8 ? (c.smax + 1 > GC_CLAIM_TAIL ? GC_CLAIM_TAIL2 : GC_CLAIM_TAIL) : 8;
+                cc.tag = (same && n + 2 * c.smax - cc.jsum <= tmax) ? 1 : 0;
                 cc.n = n;
                 cc.lo = end;
                 cc.hi = other;

@@ -58,6 +58,7 @@ struct SpecChan {               // a channel's constants for the discovery passe
     GcCarStepC CK;
     double ci, spc, ps, dlen;
     int clen, smax;
+    int tmax;                   // tail positions of the chain's instance for this channel (plan2_class)
     bool ok;
 };
 
@@ -69,6 +70,7 @@ __device__ __forceinline__ void spec_chan_init(SpecChan &C, const GcChan &c, con
     C.clen = c.clen;
     C.smax = c.smax;
     C.ps = gc_carrier_ps(s.carrfreq, c.ti);
+    C.tmax = c.smax + 1 > 8 ? (c.smax + 1 > GC_CLAIM_TAIL ? GC_CLAIM_TAIL2 : GC_CLAIM_TAIL) : 8;
     C.ok = C.ci > 0.0 && C.ci < C.dlen && C.spc > 1e-300 && C.spc < 1e300;
     if (!C.ok) return;
     gc_code_plan_init(C.PC, C.ci, c.clen, c.smax);
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(GC_SPEC_CHUNK) void trk_spec_kernel(const GcChan *_
             const bool side = (lo - C.PC.smaxci < 0.0) == (hi - C.PC.smaxci < 0.0);     // (ref src/sdrcmn.c:614: one branch for the whole bracket)
             const bool oklo = gc_code_claims<true>(C.PC, lo, nlo + 2 * C.smax, cc, &dummy);
             const bool okhi = oklo && gc_code_claims<false>(C.PC, hi, nlo + 2 * C.smax, cc, &dummy);
-            if (side && oklo && okhi) {
+            // (the discovering step allows the widest tail; the chain's instance for this channel may be narrower, and
+            // in its value form nothing would notice a tail it cannot hold)
+            const bool tailfits = nlo + 2 * C.smax - cc.jsum <= C.tmax;
+            if (side && oklo && okhi && tailfits) {
                 bracketed = true;
                 ncode = nlo;
                 cc.tag = 1;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(GC_SPEC_CHUNK) void trk_spec_kernel(const GcChan *_
             cc.tag = 0;
             if (ncode > 0 && ncode <= (1 << 24)) {
                 double dummy;
-                cc.tag = gc_code_claims<true>(C.PC, rt, ncode + 2 * C.smax, cc, &dummy) ? 3 : 0;
+                cc.tag = (gc_code_claims<true>(C.PC, rt, ncode + 2 * C.smax, cc, &dummy) && ncode + 2 * C.smax - cc.jsum <= C.tmax) ? 3 : 0;
             }
             cc.n = ncode;
             cc.lo = cc.hi = rt;
