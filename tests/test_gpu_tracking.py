@@ -291,6 +291,29 @@ def test_planner_chain_long_batch(gc, orc, engine):
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
 
 
+def test_planner_batch_lengths_at_the_kernels_block_edges(gc, orc, engine):
+    """Back-to-back batches of 1, 2, 63, 64, 65, 255, 256, 257 and 3 periods (the chain works in blocks of 64 periods,
+    the discovery in chunks of 256; every change of length also drops the look-ahead plan and discovery): every
+    batch's sums, sample counts and the final state against the oracle's literal loop."""
+    lengths = (1, 2, 63, 64, 65, 255, 256, 257, 3)
+    total = sum(lengths)
+    nsamples = 16368 * (total + 12)
+    data, chans, states, ochs = _setup(gc, orc, engine, 2, 0.0, 2, 3, 3, prns=[2, 19, 28], nsamples=nsamples, seed=321, buffloc0=9)
+    states[1]["carrfreq"] = -4321.5          # one falling phase (a period inside one binade), one fast rising one
+    states[2]["carrfreq"] = 8765.25
+    engine.trk_set_state(states)
+    oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, total)
+    done = 0
+    for n in lengths:
+        engine.trk_run(n)
+        II, QQ, ns = engine.trk_fetch()
+        assert np.array_equal(ns, ons[:, done:done + n]), n
+        assert np.array_equal(II, oII[:, done:done + n]) and np.array_equal(QQ, oQQ[:, done:done + n]), n
+        done += n
+    for a, b in zip(engine.trk_get_state(), ofin):
+        assert a["remcode"] == b["remcode"] and a["remcarr"] == b["remcarr"] and a["buffloc"] == b["buffloc"]
+
+
 def test_planner_brackets_hold_under_the_checks(gc, orc, engine, tmp_path):
     """The batch planner's chain evaluates a period WITHOUT its checks when the period's exact start lies inside the
     bracket the discovery proved the claims for (gnsscorr_plan.hip).  GNSSCORR_PLAN_VERIFY=1 makes the chain run
