@@ -732,12 +732,72 @@ __device__ __attribute__((noinline)) int plan4_car_other(double ps_, int nsamp_,
     return plan2_car_slow(ps_, remcarr_, n_, lane, out);
 }
 
+// The carrier chain of a channel whose periods the discovery has no claims for (a real front end at 4 MHz IF: the
+// phase climbs thirteen binades per period from below the table): the certified step for every period, its tables
+// in registers for the batch -- what the chain of round 2 did for such channels (3.4 us per period), instead of the
+// off-path call per period.
+__device__ __attribute__((noinline)) void plan4_car_cert_wave(double ps_, const Plan4Job *J_, int lane)
+{
+    const double ps = plan2_uni(ps_);
+    const Plan4Job J = plan4_job(J_);
+    GcCarPlan PK;
+    gc_car_plan_init(PK, ps);
+    GcFillLanes fill{lane};
+    GcNoEmit ne;
+    const double ydpi = __ddiv_rn(1.0, GC_NCO_DPI);
+    unsigned tally1 = 0, tally2 = 0;
+    GC_GLOBAL GcTrkPlan *out = (GC_GLOBAL GcTrkPlan *)J.out;
+    double remcarr = J.s.remcarr;
+    int seen = 0;
+    for (int b = 0; b < J.nblk; b++) {
+        const int nb = plan4_nb(J, b), e0 = b * GC_P4_BLK;
+        for (int i = 0; i < nb; i++) {
+            while (seen <= e0 + i) {
+                seen = plan2_uni(plan4_progress());
+                if (seen <= e0 + i) __builtin_amdgcn_s_sleep(1);
+            }
+            const int n = plan2_uni(g_plan4.nsh[e0 + i]);
+            if (lane == 0) g_plan4.vstart[1][i] = remcarr;
+            if (n > 0 && n <= (1 << 24)) {
+                double rp;
+                if (gc_carrier_period(PK, remcarr, n, fill, &rp)) {
+                    tally1++;
+                } else {
+                    const double phis = gc_div_y(__dmul_rn(remcarr, GC_NCO_CDIV), GC_NCO_DPI, ydpi);      // ref src/sdrcmn.c:649
+                    double xn;
+                    if (!plan_carrier_dev(PK.f, phis, n, g_plan4.Ks2[1], lane, &xn)) xn = gc_fast_carrier_walk(PK.f, phis, n, ne);
+                    rp = gc_fast_prem(PK.fprem, xn);
+                    tally2++;
+                }
+                remcarr = rp;
+            }
+        }
+        if (lane < nb) out[e0 + lane].phi0 = g_plan4.vstart[1][lane];
+    }
+    if (lane == 0) {
+        ((GC_GLOBAL GcTrkState *)J.state_out)->remcarr = remcarr;
+        if (tally1) atomicAdd(&gc_plan_stats[4], (unsigned long long)tally1);
+        if (tally2) atomicAdd(&gc_plan_stats[5], (unsigned long long)tally2);
+    }
+}
+
 // The carrier NCO's chain, behind the code's
 __device__ __attribute__((noinline)) void plan4_car_wave(double ps_, int nsamp_, const Plan4Job *J_, int lane)
 {
     const int nsamp = plan2_uni(nsamp_);
     const double ps = plan2_uni(ps_);
     const Plan4Job J = plan4_job(J_);
+    {
+        // a channel the discovery has no carrier claims for at all (its first periods say so): the certifying chain
+        const int nlook = J.nepoch < 16 ? J.nepoch : 16;
+        int none = 0;
+        for (int e = 0; e < nlook; e++)
+            none += ((const GC_CONST int *)J.claims_car)[(size_t)e * GC_CLAIM_ROW] == 0 ? 1 : 0;
+        if (none == nlook && nlook >= 8) {
+            plan4_car_cert_wave(ps, J_, lane);
+            return;
+        }
+    }
     {
         GcCarPlan full;
         gc_car_plan_init(full, ps);

@@ -7,13 +7,14 @@ import gnsscorr_loader
 gc = gnsscorr_loader.load()
 NS, E = 16368, 1000
 rng = np.random.default_rng(20240601)
-data = np.random.default_rng(3).integers(-60, 61, size=((E + 4) * NS, 2), dtype=np.int8)
+DTYPE, F_IF = int(os.environ.get("DTYPE", "2")), float(os.environ.get("F_IF", "0"))
+data = np.random.default_rng(3).integers(-60, 61, size=((E + 4) * NS, 2) if DTYPE == 2 else ((E + 4) * NS,), dtype=np.int8)
 eng = gc.Engine(0)
-eng.ring_create(1, 2, data.shape[0]); eng.ring_push_raw(1, data, data.shape[0])
+eng.ring_create(1, DTYPE, data.shape[0]); eng.ring_push_raw(1, data, data.shape[0])
 NCH = int(os.environ.get('NCH', '32'))
-chans = [gc.Channel(p, dtype=2, f_if=0.0, corrn=2, corrd=3, corrp=3) for p in range(1, NCH + 1)]
+chans = [gc.Channel(p, dtype=DTYPE, f_if=F_IF, corrn=2, corrd=3, corrp=3) for p in range(1, NCH + 1)]
 eng.set_channels(chans)
-st0 = [dict(carrfreq=float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)), remcode=float(rng.uniform(0.01, 0.99)),
+st0 = [dict(carrfreq=F_IF + float(rng.uniform(-5000, 5000)), codefreq=c.crate + float(rng.uniform(-2, 2)), remcode=float(rng.uniform(0.01, 0.99)),
             remcarr=float(rng.uniform(0, 6.2)), buffloc=int(rng.integers(0, NS))) for c in chans]
 eng.timing(1)
 for rep in range(4):
