@@ -224,6 +224,60 @@ def test_closed_loop_bench_configuration_32_channels(gc, orc, synth, engine):
     _check_against_oracle(orc, engine, ochs, ring, bufflocs, 30, 5, done=320)
 
 
+@pytest.mark.parametrize("seed,dtype,f_if,f_sf,taps,flagsync", [
+    (101, 2, 0.0, 16.368e6, (2, 3, 3), 1),
+    (102, 2, 0.0, 16.368e6, (6, 3, 6), 0),
+    (103, 1, 4.092e6, 16.368e6, (2, 3, 3), 1),
+    (104, 1, 4.092e6, 16.368e6, (1, 8, 8), 0),
+    (105, 2, 0.0, 4.092e6, (2, 1, 1), 1),
+    (106, 2, 0.0, 20.0e6, (2, 3, 3), 1),
+    (107, 2, 0.0, 20.0e6, (6, 3, 6), 0),
+])
+def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtype, f_if, f_sf, taps, flagsync):
+    """Closed loop from random start states on noise (no satellite: the filters wander), per front end of the
+    shipped configurations -- int8 IQ at 16.368, 4.092 and 20 Msps, real samples at a 4.092 MHz IF -- with 3-, 5- and
+    13-tap sets, before (filter update every period) and after nav bit synchronisation (every 10 periods: intervals
+    planned from claims discovered for brackets around the closed-form period starts, gnsscorr_loop.hip).  Starts
+    include a remainder of exactly 0, remainders within 1e-6 of 0 and of 1 chip, a carrier phase of 0 and Doppler up
+    to +-9 kHz.  12 channels x 130 periods in two runs, everything bit for bit against orc_sdrthread_step."""
+    corrn, corrd, corrp = taps
+    nper, nch = 130, 12
+    nsamp = int(f_sf * 1e-3)
+    rng = np.random.default_rng(seed)
+    nsamples = nsamp * (nper + 4)
+    data = rng.integers(-60, 61, size=(nsamples, 2) if dtype == 2 else (nsamples,), dtype=np.int8)
+    engine.ring_create(1, dtype, nsamples)
+    engine.ring_push_raw(1, data, nsamples)
+    prns = [1 + (3 * i) % 32 for i in range(nch)]
+    chans = [gc.Channel(p, dtype=dtype, f_if=f_if, f_sf=f_sf, corrn=corrn, corrd=corrd, corrp=corrp) for p in prns]
+    engine.set_channels(chans)
+    ring = orc.make_ring(data, nsamples, nsamples)
+    states0, ochs, bufflocs, loops = [], [], [], []
+    for i, c in enumerate(chans):
+        edge = i % 4
+        remcode = (0.0 if edge == 0 else float(rng.uniform(0.0, 1e-6)) if edge == 1 else
+                   float(1.0 - rng.uniform(0.0, 1e-6)) if edge == 2 else float(rng.uniform(0.01, 0.99)))
+        st = dict(carrfreq=f_if + float(rng.uniform(-9000, 9000)), codefreq=c.crate + float(rng.uniform(-6, 6)),
+                  remcode=remcode, remcarr=float(rng.uniform(0, 6.2)) if i % 5 else 0.0, buffloc=int(rng.integers(0, nsamp)))
+        states0.append(st)
+        acqfreq = f_if + 200.0 * round((st["carrfreq"] - f_if) / 200.0)
+        o = orc.make_chan(c.prn, dtype=dtype, f_sf=f_sf, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
+        o.acq.acqfreq = acqfreq
+        o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
+        o.flagsync, o.synci, o.cnt = flagsync, (3 + 7 * i) % 20, 2001 + 3 * i
+        ochs.append(o)
+        bufflocs.append(C.c_uint64(st["buffloc"]))
+        loops.append(engine.loop_state(i, acqfreq, flagsync=flagsync, synci=o.synci, cnt=o.cnt))
+    engine.trk_set_state(states0)
+    engine.loop_set(loops)
+    ntap = 1 + 2 * corrn
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 97, ntap)
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 33, ntap, done=97)
+    fin = engine.trk_get_state()
+    for i, o in enumerate(ochs):
+        assert fin[i]["buffloc"] == bufflocs[i].value and fin[i]["remcode"] == o.remcode and fin[i]["remcarr"] == o.remcarr
+
+
 def test_closed_loop_tie_in_the_top_binade_state(gc, orc, engine):
     """The single state on which the round-2 closed-loop kernel stalled (tools/debug/loop_hang3.py): a chip step
     that is a rounding tie in the code's top binade, so the period step falls back to the general walkers, and a
