@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <unistd.h>
 
 #include "../../include/sdr_compat.h"
@@ -192,6 +193,7 @@ struct TrkReq {
     uint64_t buffloc;
     int n;
     double cI[GNSSCORR_MAXTAPS], cQ[GNSSCORR_MAXTAPS];
+    unsigned long codesum;          // hash of sdr->code[0..clen), computed by the calling thread (cmb_code)
     int rc;
     bool done;
     char err[200];
@@ -205,18 +207,37 @@ struct TrkCombiner {
     std::vector<TrkReq *> queue;
     bool leader = false;
     std::map<sdrch_t *, CodeSlot> codes;
-    // device / pinned staging for `cap` requests
+    // device / pinned staging for `cap` requests.  One pinned block goes down per launch chain (the requests' GcChan
+    // and GcTrkPlan records, side by side); the results come back without a copy: trk_finish writes the sums into
+    // pinned host memory (hres), and the piece-table overflow counter lives there too (hover).
     int cap = 0, nseg_cap = 0, ntap_cap = 0;
-    GcChan *dchan = nullptr, *hchan = nullptr;
-    GcTrkPlan *dplan = nullptr, *hplan = nullptr;
+    char *dstage = nullptr, *hstage = nullptr;
     GcTrkUnit *dunit = nullptr;
     GcUnitSegs *dsegs = nullptr;
     GcRound *drounds = nullptr;
-    int *dpartial = nullptr, *doverflow = nullptr;
-    double *dout = nullptr, *hout = nullptr;          // corrI[cap][ntap], corrQ[cap][ntap], sumI, sumQ
+    int *dpartial = nullptr;
+    double *dsum = nullptr;                             // sumI[cap][ntap], sumQ[cap][ntap] (device; unused by sdrtracking)
+    double *hres = nullptr, *hres_dev = nullptr;        // corrI[cap][ntap], corrQ[cap][ntap] (pinned, written by the device)
+    int *hover = nullptr, *hover_dev = nullptr;         // NCO piece-table overflow (pinned)
     unsigned long long *dfinish = nullptr;
 };
 TrkCombiner g_cmb;
+
+// GNSSCORR_CMB_PROF=1: where a combined launch chain's host time goes, printed when the process ends
+struct CmbProf {
+    bool on = getenv("GNSSCORR_CMB_PROF") != nullptr;
+    unsigned long long batches = 0, reqs = 0;
+    double t[5] = {0, 0, 0, 0, 0};
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+    ~CmbProf()
+    {
+        if (on && batches)
+            fprintf(stderr, "gnsscorr combiner: %llu launch chains, %.1f requests each; us per chain: prepare %.1f, enqueue %.1f, "
+                            "wait %.1f, hand out %.1f, whole cmb_run %.1f\n", batches, (double)reqs / batches, t[0] / batches,
+                    t[1] / batches, t[2] / batches, t[3] / batches, t[4] / batches);
+    }
+};
+CmbProf g_cprof;
 
 int cmb_reserve(gnsscorr_ctx *ctx, int k, int nseg, int ntap)
 {
@@ -227,31 +248,33 @@ int cmb_reserve(gnsscorr_ctx *ctx, int k, int nseg, int ntap)
     // call -- capacities are zero -- starts over)
     auto dfree = [](auto *&p) { if (p) hipFree(p); p = nullptr; };
     auto hfree = [](auto *&p) { if (p) hipHostFree(p); p = nullptr; };
-    dfree(q.dchan); dfree(q.dplan); dfree(q.dunit); dfree(q.dsegs); dfree(q.drounds); dfree(q.dpartial);
-    dfree(q.dout); dfree(q.dfinish); dfree(q.doverflow);
-    hfree(q.hchan); hfree(q.hplan); hfree(q.hout);
+    dfree(q.dstage); dfree(q.dunit); dfree(q.dsegs); dfree(q.drounds); dfree(q.dpartial);
+    dfree(q.dsum); dfree(q.dfinish);
+    hfree(q.hstage); hfree(q.hres); hfree(q.hover);
+    q.hres_dev = nullptr; q.hover_dev = nullptr;
     const int cap = k > 64 ? k : 64, ns = nseg > 1 ? nseg : 1, nt = GNSSCORR_MAXTAPS;
     q.cap = q.nseg_cap = q.ntap_cap = 0;
-    GC_HIP(hipMalloc((void **)&q.dchan, sizeof(GcChan) * cap));
-    GC_HIP(hipMalloc((void **)&q.dplan, sizeof(GcTrkPlan) * cap));
+    const size_t stage = (sizeof(GcChan) + sizeof(GcTrkPlan)) * cap + 64;
+    GC_HIP(hipMalloc((void **)&q.dstage, stage));
     GC_HIP(hipMalloc((void **)&q.dunit, sizeof(GcTrkUnit) * cap));
     GC_HIP(hipMalloc((void **)&q.dsegs, sizeof(GcUnitSegs) * cap));
     GC_HIP(hipMalloc((void **)&q.drounds, sizeof(GcRound) * cap * ns * GC_MAXR));
     GC_HIP(hipMalloc((void **)&q.dpartial, sizeof(int) * cap * ns * 2 * nt));
-    GC_HIP(hipMalloc((void **)&q.dout, sizeof(double) * cap * 4 * nt));
+    GC_HIP(hipMalloc((void **)&q.dsum, sizeof(double) * cap * 2 * nt));
     GC_HIP(hipMalloc((void **)&q.dfinish, sizeof(unsigned long long) * cap * GC_FINISH_SCRATCH));
-    GC_HIP(hipMalloc((void **)&q.doverflow, sizeof(int)));
     GC_HIP(hipMemsetAsync(q.dfinish, 0, sizeof(unsigned long long) * cap * GC_FINISH_SCRATCH, ctx->stream));
-    GC_HIP(hipMemsetAsync(q.doverflow, 0, sizeof(int), ctx->stream));
-    GC_HIP(hipHostMalloc((void **)&q.hchan, sizeof(GcChan) * cap));
-    GC_HIP(hipHostMalloc((void **)&q.hplan, sizeof(GcTrkPlan) * cap));
-    GC_HIP(hipHostMalloc((void **)&q.hout, sizeof(double) * cap * 4 * nt + 64));
+    GC_HIP(hipHostMalloc((void **)&q.hstage, stage));
+    GC_HIP(hipHostMalloc((void **)&q.hres, sizeof(double) * cap * 2 * nt, hipHostMallocMapped));
+    GC_HIP(hipHostGetDevicePointer((void **)&q.hres_dev, q.hres, 0));
+    GC_HIP(hipHostMalloc((void **)&q.hover, 64, hipHostMallocMapped));
+    GC_HIP(hipHostGetDevicePointer((void **)&q.hover_dev, q.hover, 0));
+    *q.hover = 0;
     q.cap = cap; q.nseg_cap = ns; q.ntap_cap = nt;
     return 0;
 }
 
 // the channel's code block on the device (uploaded when the code of this sdrch_t is first seen or changes)
-int cmb_code(gnsscorr_ctx *ctx, sdrch_t *sdr, CodeSlot **out)
+int cmb_code(gnsscorr_ctx *ctx, sdrch_t *sdr, unsigned long sum, CodeSlot **out)
 {
     // (keyed by the caller's sdrch_t: a receiver has at most MAXSAT of them; a caller that keeps handing in new structs
     // gets the table emptied instead of growing without bound -- the stream is idle here, every call ends synchronised)
@@ -260,8 +283,6 @@ int cmb_code(gnsscorr_ctx *ctx, sdrch_t *sdr, CodeSlot **out)
         g_cmb.codes.clear();
     }
     CodeSlot &cs = g_cmb.codes[sdr];
-    unsigned long sum = 0;          // (unsigned: the hash wraps)
-    for (int i = 0; i < sdr->clen; i++) sum = sum * 31u + (unsigned long)(unsigned short)sdr->code[i];
     if (!cs.dcode || cs.sum != sum || cs.clen != sdr->clen) {
         if (!cs.dcode) GC_HIP(hipMalloc((void **)&cs.dcode, GC_CODEBLOCK));
         int8_t block[GC_CODEBLOCK];
@@ -289,13 +310,17 @@ int cmb_run_group(gnsscorr_ctx *ctx, std::vector<TrkReq *> &grp)
     const int nseg = gc_trk_nseg(dtype, max_n);
     int rc = cmb_reserve(ctx, k, nseg, ntap);
     if (rc) return rc;
+    const double tp0 = g_cprof.on ? CmbProf::now() : 0.0;
+    const size_t plan_off = (sizeof(GcChan) * (size_t)k + 63) & ~(size_t)63;
+    GcChan *hchan = reinterpret_cast<GcChan *>(q.hstage), *dchan = reinterpret_cast<GcChan *>(q.dstage);
+    GcTrkPlan *hplan = reinterpret_cast<GcTrkPlan *>(q.hstage + plan_off), *dplan = reinterpret_cast<GcTrkPlan *>(q.dstage + plan_off);
     for (int i = 0; i < k; i++) {
         sdrch_t *sdr = grp[i]->sdr;
         const GcRing &ring = ctx->ring[sdr->ftype == FTYPE2 ? 1 : 0];
         CodeSlot *cs;
-        rc = cmb_code(ctx, sdr, &cs);
+        rc = cmb_code(ctx, sdr, grp[i]->codesum, &cs);
         if (rc) return rc;
-        GcChan &c = q.hchan[i];
+        GcChan &c = hchan[i];
         memset(&c, 0, sizeof(c));
         c.ring = ring.mem; c.ringlen = ring.ringlen; c.code = cs->dcode;
         c.dtype = dtype; c.clen = sdr->clen; c.nsamp = grp[i]->n; c.ntap = ntap;
@@ -304,39 +329,45 @@ int cmb_run_group(gnsscorr_ctx *ctx, std::vector<TrkReq *> &grp)
         for (int t = 0; t < sdr->trk.corrn; t++) { c.tapoff[1 + 2 * t] = -sdr->trk.corrp[t]; c.tapoff[2 + 2 * t] = sdr->trk.corrp[t]; }
         c.ti = sdr->ti;
         c.nedge = cs->nedge; c.pm1 = cs->pm1;
-        GcTrkPlan &p = q.hplan[i];
+        GcTrkPlan &p = hplan[i];
         memset(&p, 0, sizeof(p));
         p.buffloc = grp[i]->buffloc; p.coff = sdr->trk.oldremcode; p.phi0 = sdr->trk.oldremcarr;
         p.carrfreq = sdr->trk.carrfreq; p.codefreq = sdr->trk.codefreq; p.n = grp[i]->n;
     }
     hipStream_t st = ctx->stream;
-    GC_HIP(hipMemcpyAsync(q.dchan, q.hchan, sizeof(GcChan) * k, hipMemcpyHostToDevice, st));
-    GC_HIP(hipMemcpyAsync(q.dplan, q.hplan, sizeof(GcTrkPlan) * k, hipMemcpyHostToDevice, st));
-    rc = gc_launch_trk_expand(st, q.dchan, q.dplan, q.dunit, q.dsegs, nullptr, k, 1, q.drounds, nseg, max_n, q.doverflow);
+    const double tp1 = g_cprof.on ? CmbProf::now() : 0.0;
+    GC_HIP(hipMemcpyAsync(q.dstage, q.hstage, plan_off + sizeof(GcTrkPlan) * k, hipMemcpyHostToDevice, st));
+    rc = gc_launch_trk_expand(st, dchan, dplan, q.dunit, q.dsegs, nullptr, k, 1, q.drounds, nseg, max_n, q.hover_dev);
     if (rc) return rc;
-    rc = gc_launch_trk_corr(st, q.dchan, q.dunit, q.dsegs, q.drounds, q.dpartial, k, 1, nseg, ntap, dtype, ntap, max_n, smax_max, nullptr);
+    rc = gc_launch_trk_corr(st, dchan, q.dunit, q.dsegs, q.drounds, q.dpartial, k, 1, nseg, ntap, dtype, ntap, max_n, smax_max, nullptr);
     if (rc) return rc;
-    double *cI = q.dout, *cQ = q.dout + (size_t)q.cap * ntap, *sI = cQ + (size_t)q.cap * ntap, *sQ = sI + (size_t)q.cap * ntap;
+    // (the period's sums straight into pinned host memory: no copy back)
+    double *cI = q.hres_dev, *cQ = q.hres_dev + (size_t)q.cap * ntap, *sI = q.dsum, *sQ = q.dsum + (size_t)q.cap * ntap;
     rc = gc_launch_trk_finish(st, q.dpartial, cI, cQ, sI, sQ, q.dfinish, k, 1, nseg, ntap);
     if (rc) return rc;
-    int *hover = reinterpret_cast<int *>(q.hout + (size_t)q.cap * 4 * GNSSCORR_MAXTAPS);
-    GC_HIP(hipMemcpyAsync(q.hout, cI, sizeof(double) * k * ntap, hipMemcpyDeviceToHost, st));
-    GC_HIP(hipMemcpyAsync(q.hout + (size_t)k * ntap, cQ, sizeof(double) * k * ntap, hipMemcpyDeviceToHost, st));
-    GC_HIP(hipMemcpyAsync(hover, q.doverflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    const double tp2 = g_cprof.on ? CmbProf::now() : 0.0;
     GC_HIP(hipStreamSynchronize(st));
-    if (*hover) {
-        GC_HIP(hipMemsetAsync(q.doverflow, 0, sizeof(int), st));
+    const double tp3 = g_cprof.on ? CmbProf::now() : 0.0;
+    if (*q.hover) {
+        *q.hover = 0;
         return gc_fail(GNSSCORR_EINVAL, "sdrtracking: a period needs more NCO pieces than the tables hold");
     }
     for (int i = 0; i < k; i++) {
-        memcpy(grp[i]->cI, q.hout + (size_t)i * ntap, sizeof(double) * ntap);
-        memcpy(grp[i]->cQ, q.hout + (size_t)(k + i) * ntap, sizeof(double) * ntap);
+        memcpy(grp[i]->cI, q.hres + (size_t)i * ntap, sizeof(double) * ntap);
+        memcpy(grp[i]->cQ, q.hres + (size_t)(q.cap + i) * ntap, sizeof(double) * ntap);
+    }
+    if (g_cprof.on) {
+        const double tp4 = CmbProf::now();
+        g_cprof.batches++; g_cprof.reqs += (unsigned long long)k;
+        g_cprof.t[0] += tp1 - tp0; g_cprof.t[1] += tp2 - tp1; g_cprof.t[2] += tp3 - tp2; g_cprof.t[3] += tp4 - tp3;
     }
     return 0;
 }
 
 void cmb_run(std::vector<TrkReq *> &batch)
 {
+    const double tr0 = g_cprof.on ? CmbProf::now() : 0.0;
+    struct Whole { double t0; ~Whole() { if (g_cprof.on) g_cprof.t[4] += CmbProf::now() - t0; } } whole{tr0};
     gnsscorr_ctx *ctx = gnsscorr_default_ctx();
     auto fail_all = [&](std::vector<TrkReq *> &v, const char *msg) {
         for (TrkReq *r : v) { r->rc = -1; snprintf(r->err, sizeof(r->err), "%s", msg); }
@@ -423,6 +454,8 @@ uint64_t sdrtracking(sdrch_t *sdr, uint64_t buffloc, uint64_t cnt)
                       sdr->clen, sdr->currnsamp);
             return bufflocnow;
         }
+        req.codesum = 0;                // (unsigned: the hash wraps)
+        for (int i = 0; i < sdr->clen; i++) req.codesum = req.codesum * 31u + (unsigned long)(unsigned short)sdr->code[i];
         cmb_submit(&req);
         if (req.rc) {
             SDRPRINTF("error: sdrtracking: %s\n", req.err);

@@ -323,6 +323,8 @@ def test_sdrtracking_call_rate_from_32_pthreads(gc, orc, synth, tmp_path):
     lines = out.stdout.strip().splitlines()
     rate = float([l for l in lines if l.startswith("calls_per_s")][0].split()[1])
     print(f"\nsdrtracking() from {nch} pthreads: {rate:.0f} calls/s = {rate / 32000:.2f} x real time for 32 channels")
+    if out.stderr.strip():
+        print(out.stderr.strip()[-600:])                # (GNSSCORR_CMB_PROF=1: where a combined launch chain's time goes)
     got = {int(l.split()[1]): [float(x) for x in l.split()[2:]] for l in lines if l.startswith("chk")}
     # the harness's deterministic start states
     seed = 12345
