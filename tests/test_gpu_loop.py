@@ -33,14 +33,14 @@ def _close(a, b, tol=1e-14):
 FILTER_FIELDS = ("carrfreq", "codefreq", "carrNco", "codeNco", "carrErr", "codeErr", "freqErr")
 
 
-def _adopt(o, r, where):
+def _adopt(o, r, where, tol=1e-14):
     """This period's filter outputs: equal to the oracle's to a few ulps (same inputs), then the oracle continues
     from the device's values, so that the next period starts from identical frequencies on both sides.  The nav
     bit synchronisation (flagsync, decided bits) involves no library call: exact."""
     assert r["flagsync"] == o.flagsync, (where, "flagsync")
     assert r["navbit"] == (o.bit if (o.flagsync and o.swsync) else 0), (where, "navbit")
     for f in FILTER_FIELDS:
-        assert _close(float(r[f]), getattr(o, f)), (where, f, float(r[f]), getattr(o, f))
+        assert _close(float(r[f]), getattr(o, f), tol), (where, f, float(r[f]), getattr(o, f))
         setattr(o, f, float(r[f]))
 
 
@@ -166,7 +166,7 @@ def test_closed_loop_stops_where_data_ends(gc, orc, synth, engine):
     assert np.all(ndone2 == 10)
 
 
-def _check_against_oracle(orc, engine, ochs, ring, bufflocs, nrun, ntap, done=0):
+def _check_against_oracle(orc, engine, ochs, ring, bufflocs, nrun, ntap, done=0, tol=1e-14):
     """One trk_run_loop(nrun) against nrun oracle steps per channel: sums, samples, flags and remainders bit for
     bit, filter states to 1e-12."""
     L = orc.lib()
@@ -184,7 +184,7 @@ def _check_against_oracle(orc, engine, ochs, ring, bufflocs, nrun, ntap, done=0)
             r = log[i, e]
             assert r["flagloopfilter"] == o.flagloopfilter, where
             assert r["remcode"] == o.remcode and r["remcarr"] == o.remcarr, where
-            _adopt(o, r, where)
+            _adopt(o, r, where, tol)
 
 
 def test_closed_loop_bench_configuration_32_channels(gc, orc, synth, engine):
@@ -232,6 +232,8 @@ def test_closed_loop_bench_configuration_32_channels(gc, orc, synth, engine):
     (105, 2, 0.0, 4.092e6, (2, 1, 1), 1),
     (106, 2, 0.0, 20.0e6, (2, 3, 3), 1),
     (107, 2, 0.0, 20.0e6, (6, 3, 6), 0),
+    (108, 2, 0.0, 16.368e6, (2, 3, 3), -1),         # GLONASS G1 channels (511 chips, 10-ms bits), before ...
+    (109, 2, 0.0, 16.368e6, (6, 3, 6), -2),         # ... and after nav bit synchronisation
 ])
 def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtype, f_if, f_sf, taps, flagsync):
     """Closed loop from random start states on noise (no satellite: the filters wander), per front end of the
@@ -241,6 +243,9 @@ def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtyp
     include a remainder of exactly 0, remainders within 1e-6 of 0 and of 1 chip, a carrier phase of 0 and Doppler up
     to +-9 kHz.  12 channels x 130 periods in two runs, everything bit for bit against orc_sdrthread_step."""
     corrn, corrd, corrp = taps
+    ctype = gc.CTYPE_L1CA
+    if flagsync < 0:                                    # (negative: the G1 cases)
+        ctype, flagsync = gc.CTYPE_G1, -flagsync - 1
     nper, nch = 130, 12
     nsamp = int(f_sf * 1e-3)
     rng = np.random.default_rng(seed)
@@ -248,8 +253,8 @@ def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtyp
     data = rng.integers(-60, 61, size=(nsamples, 2) if dtype == 2 else (nsamples,), dtype=np.int8)
     engine.ring_create(1, dtype, nsamples)
     engine.ring_push_raw(1, data, nsamples)
-    prns = [1 + (3 * i) % 32 for i in range(nch)]
-    chans = [gc.Channel(p, dtype=dtype, f_if=f_if, f_sf=f_sf, corrn=corrn, corrd=corrd, corrp=corrp) for p in prns]
+    prns = [1 + (3 * i) % 32 for i in range(nch)] if ctype == gc.CTYPE_L1CA else [-7 + i for i in range(nch)]   # G1: frequency numbers
+    chans = [gc.Channel(p, ctype=ctype, dtype=dtype, f_if=f_if, f_sf=f_sf, corrn=corrn, corrd=corrd, corrp=corrp) for p in prns]
     engine.set_channels(chans)
     ring = orc.make_ring(data, nsamples, nsamples)
     states0, ochs, bufflocs, loops = [], [], [], []
@@ -257,11 +262,11 @@ def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtyp
         edge = i % 4
         remcode = (0.0 if edge == 0 else float(rng.uniform(0.0, 1e-6)) if edge == 1 else
                    float(1.0 - rng.uniform(0.0, 1e-6)) if edge == 2 else float(rng.uniform(0.01, 0.99)))
-        st = dict(carrfreq=f_if + float(rng.uniform(-9000, 9000)), codefreq=c.crate + float(rng.uniform(-6, 6)),
+        st = dict(carrfreq=f_if + c.foffset + float(rng.uniform(-9000, 9000)), codefreq=c.crate + float(rng.uniform(-6, 6)),
                   remcode=remcode, remcarr=float(rng.uniform(0, 6.2)) if i % 5 else 0.0, buffloc=int(rng.integers(0, nsamp)))
         states0.append(st)
-        acqfreq = f_if + 200.0 * round((st["carrfreq"] - f_if) / 200.0)
-        o = orc.make_chan(c.prn, dtype=dtype, f_sf=f_sf, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
+        acqfreq = f_if + c.foffset + 200.0 * round((st["carrfreq"] - f_if - c.foffset) / 200.0)
+        o = orc.make_chan(c.prn, ctype=ctype, dtype=dtype, f_sf=f_sf, f_if=f_if, corrn=corrn, corrd=corrd, corrp=corrp)
         o.acq.acqfreq = acqfreq
         o.carrfreq, o.codefreq, o.remcode, o.remcarr = st["carrfreq"], st["codefreq"], st["remcode"], st["remcarr"]
         o.flagsync, o.synci, o.cnt = flagsync, (3 + 7 * i) % 20, 2001 + 3 * i
@@ -271,8 +276,10 @@ def test_closed_loop_random_states_across_front_ends(gc, orc, engine, seed, dtyp
     engine.trk_set_state(states0)
     engine.loop_set(loops)
     ntap = 1 + 2 * corrn
-    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 97, ntap)
-    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 33, ntap, done=97)
+    # (filter outputs: the device's atan / atan2 and glibc's differ by an ulp now and then, times the loop gains -- 1e-13
+    # relative here, north_star's bound is 1e-4; everything the correlators return stays exact)
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 97, ntap, tol=1e-12)
+    _check_against_oracle(orc, engine, ochs, ring, bufflocs, 33, ntap, done=97, tol=1e-12)
     fin = engine.trk_get_state()
     for i, o in enumerate(ochs):
         assert fin[i]["buffloc"] == bufflocs[i].value and fin[i]["remcode"] == o.remcode and fin[i]["remcarr"] == o.remcarr
