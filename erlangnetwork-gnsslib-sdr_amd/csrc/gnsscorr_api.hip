@@ -851,7 +851,7 @@ static int ensure_step_buffers(gnsscorr_ctx *ctx)
     GC_HIP(hipMalloc((void **)&ctx->dstep_meta, sizeof(GcStepMeta) * ctx->nch));
     GC_HIP(hipMalloc((void **)&ctx->dstep_unit, sizeof(GcTrkUnit) * units));
     GC_HIP(hipMalloc((void **)&ctx->dstep_segs, sizeof(GcUnitSegs) * units));
-    GC_HIP(hipMalloc((void **)&ctx->dstep_rounds, sizeof(GcRound) * units * nseg));
+    GC_HIP(hipMalloc((void **)&ctx->dstep_rounds, sizeof(GcRound) * units * nseg * 4));        // four rounds (one per wavefront) per workgroup
     GC_HIP(hipMalloc((void **)&ctx->dstep_partial, sizeof(int) * units * nseg * 2 * ctx->ntap));
     if (!ctx->hostflags) {
         GC_HIP(hipHostMalloc((void **)&ctx->hostflags, 64, hipHostMallocMapped));

@@ -95,7 +95,7 @@ struct gnsscorr_ctx {
     GcStepMeta *dstep_meta = nullptr;              // [nch]
     GcTrkUnit *dstep_unit = nullptr;               // [nch][GC_STEP_KMAX]
     GcUnitSegs *dstep_segs = nullptr;
-    GcRound *dstep_rounds = nullptr;               // [nch][GC_STEP_KMAX][step_nseg]
+    GcRound *dstep_rounds = nullptr;               // [nch][GC_STEP_KMAX][step_nseg][4]
     int *dstep_partial = nullptr;                  // [nch][GC_STEP_KMAX][step_nseg][2*ntap]
     int step_nseg = 0;
     unsigned *hostflags = nullptr;                 // pinned, device-visible: [0] channels whose run is over, [1] some channel has its nav bit synchronised

@@ -123,7 +123,7 @@ int gc_fail(int code, const char *fmt, ...);
 
 // One round of the prefix-sum correlator (gnsscorr_trk.hip): the chip edges [q0, q1) its samples can
 // touch, in the numbering period * nedge + list index, and the value of its last chip.
-#define GC_MAXR 16
+#define GC_MAXR 24
 struct GcRound {
     int q0, q1;         // edges [q0, q1)
     short clast, w0;    // value of the round's last chip; whole code periods in front of edge q0

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
     GC_TSTAMP(5);       // tables
     // ---- out: per period the invariants, the rounds, the copy to the correlator's buffers ---------------------------
     const int k = S.k;
-    const int nit = trk_ps_nit(dtype, 2), rgrp = 256 * nit, rsamp = rgrp * (16 / dtype);
+    const int nit = trk_ps_nit(dtype, 2), rgrp = GC_PS_WLANES * nit, rsamp = rgrp * (16 / dtype);     // a round: one wavefront's share (gnsscorr_ps.h)
     for (int e = wave; e < k; e += GC_TAIL_NW) {
         const int n = S.n[e], nt = n + 2 * c.smax;
         const int p = m.done + e;
@@ -914,9 +914,9 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                 sg.j0 = scode[lane].j0; sg.cnt = scode[lane].cnt; sg.w = scode[lane].w; sg.pad = 0;
                 gs->code[lane] = sg;
             }
-            // rounds: one per correlator workgroup (lane = round)
+            // rounds: four per correlator workgroup, one per wavefront (lane = round)
             const int g0 = lane * rgrp;
-            if (lane < nseg && g0 < u.G) {
+            if (lane < 4 * nseg && g0 < u.G) {
                 const unsigned short *rank = (const unsigned short *)(c.code + 1024);
                 const int kl = (g0 * 16 - u.head) / dtype;
                 const int kfirst = kl > 0 ? kl : 0;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
                 ro.clast = (short)c.code[mb];
                 ro.w0 = (short)wa;
                 ro.hint = hint;
-                rounds[ui * nseg + lane] = ro;
+                rounds[ui * nseg * 4 + lane] = ro;
             }
         }
         if (lane == 0) {
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(64 * GC_TAIL_NW) void trk_step_tail_kernel(
     GC_TSTAMP(7);       // state out
 }
 
-// (channel, period of its interval, round) -> one workgroup: ps_unit on one round of the period
+// (channel, period of its interval, quarter) -> one workgroup: ps_unit on four rounds of the period, one per wavefront
 template <int DTYPE, int NTAP, int NIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTAP <= 7 ? 4 : (NTAP <= 13 ? 3 : (NTAP <= 21 ? 2 : 1)), 8)))
 void trk_step_corr_kernel(const GcChan *__restrict__ chan, const GcStepMeta *__restrict__ meta, const GcTrkUnit *__restrict__ unit,
@@ -992,8 +992,8 @@ void trk_step_corr_kernel(const GcChan *__restrict__ chan, const GcStepMeta *__r
     if (e >= meta[ch].k) return;
     const size_t ui = (size_t)ch * kcap + e;
     const GcTrkUnit u = unit[ui];
-    ps_unit<DTYPE, NTAP, NIT>(c, u, segs + ui, rounds + (ui * nseg + seg), partial + (ui * nseg + seg) * 2 * ntap_stride,
-                              ntap_stride, max_n, 1, seg, 0, smem, tid, nullptr);
+    ps_unit<DTYPE, NTAP, NIT>(c, u, segs + ui, rounds + (ui * nseg + seg) * 4, partial + (ui * nseg + seg) * 2 * ntap_stride,
+                              ntap_stride, max_n, 4, seg, 0, smem, tid, nullptr);
 }
 
 template <int DTYPE>
@@ -1016,7 +1016,7 @@ int launch_step_corr(hipStream_t st, const GcChan *chan, const GcStepMeta *meta,
 
 }  // namespace
 
-// rounds (= workgroups) per period in step mode: one round each
+// workgroups per period in step mode: four rounds (one per wavefront) each
 int gc_step_nseg(int dtype, int max_n)
 {
     const int nit = trk_ps_nit(dtype, 2);

@@ -20,11 +20,13 @@ extern "C" int gnsscorr_debug_ps_trace(unsigned long long *dst)
 
 namespace {
 
-// rounds per workgroup of the prefix-sum correlator: a whole period when it fits GC_MAXR rounds
+// A round of the prefix-sum correlator is what ONE wavefront mixes, scans and looks up on its own: 64 * nit sample
+// groups.  Rounds per workgroup: a whole period when it fits GC_MAXR rounds (the workgroup's four wavefronts share them).
+#define GC_PS_WLANES 64
 __host__ __device__ inline int trk_ps_rounds(int dtype, int max_n, int nit)
 {
     const int groups = (15 + max_n * dtype + 15) / 16 + 1;
-    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
+    const int rounds = (groups + GC_PS_WLANES * nit - 1) / (GC_PS_WLANES * nit);
     const int nseg = (rounds + GC_MAXR - 1) / GC_MAXR;
     return (rounds + nseg - 1) / nseg;
 }
@@ -128,21 +130,23 @@ template <int DTYPE, int NIT>
 struct PsLayout {
     static constexpr int SPG = 16 / DTYPE;                      // samples per 16-byte group
     static constexpr int LSP = NIT * SPG;                       // samples per lane and round
-    static constexpr int RGRP = 256 * NIT;                      // groups per round
-    static constexpr int RSAMP = 256 * LSP;                     // samples per round
+    static constexpr int RGRP = GC_PS_WLANES * NIT;             // groups per round (one wavefront)
+    static constexpr int RSAMP = GC_PS_WLANES * LSP;            // samples per round
     static constexpr int LPAD = LSP + 1;                        // image stride per lane: odd in 8-byte units
     static constexpr int MAXR = GC_MAXR;                        // rounds per workgroup, at most
     static constexpr int LUTPOS = DTYPE == 2 ? 2 : 4;
     static constexpr int LUT_BYTES = 32 * 8 * LUTPOS;
-    static constexpr int WT_OFF = LUT_BYTES;                    // wpre[2][8] int2 (two rounds in flight)
-    static constexpr int LB_OFF = WT_OFF + 128;
-    static constexpr int LOC_OFF = LB_OFF + ((257 * 8 + 15) & ~15);
+    // per wavefront: lbase[64 + 1] and the prefix image loc[64 lanes][LPAD] + closing entry
+    static constexpr int LB_WAVE = (GC_PS_WLANES + 1) * 8;
+    static constexpr int LOC_WAVE = (GC_PS_WLANES * LPAD + 1) * 8;
+    static constexpr int LB_OFF = LUT_BYTES;
+    static constexpr int LOC_OFF = LB_OFF + ((4 * LB_WAVE + 15) & ~15);
     // the unit's NCO tables: carrier piece starts (+ closing sentinel), carrier pieces, code pieces
-    static constexpr int K0_OFF = LOC_OFF + (((256 * LPAD + 1) * 8 + 15) & ~15);
+    static constexpr int K0_OFF = LOC_OFF + ((4 * LOC_WAVE + 15) & ~15);
     static constexpr int CAR_OFF = K0_OFF + (((GC_NCAR + 1) * 4 + 15) & ~15);
     static constexpr int CODE_OFF = CAR_OFF + GC_NCAR * (int)sizeof(GcCarSeg);
     static constexpr int RED_OFF = CODE_OFF + GC_NCODE * (int)sizeof(GcCodeSeg);
-    static constexpr int bytes(int ntap) { return RED_OFF + 4 * 2 * ntap * 4 + 16; }
+    static constexpr int bytes(int ntap) { return RED_OFF + 4 * (2 * ntap + 2) * 4 + 16; }
 };
 
 // a . b over four int8 lanes + c into a NEW register (the three-operand form, by name: through the builtin the compiler
@@ -167,8 +171,13 @@ __device__ __forceinline__ int wave_scan(int v)     // inclusive prefix sum over
 }
 
 // One (channel, period) unit [or a long period's share `seg` of it] on one 256-lane workgroup: the body of
-// trk_corr_ps_kernel, also called period by period from the closed-loop kernel.  smem: PsLayout bytes.
-// Every lane of the workgroup must call it (it synchronises the workgroup).
+// trk_corr_ps_kernel, also called from the closed-loop step kernel.  smem: PsLayout bytes.
+// Every lane of the workgroup must call it (it synchronises the workgroup twice: tables in, sums out).
+//
+// The workgroup's rounds are independent pieces of work -- each has its own prefix image, its own edge range
+// [q0, q1) and its own closing term -- so each WAVEFRONT takes rounds of its own (wave w: rounds w, w + 4, ...) and
+// runs them from the samples to the tap accumulators without meeting the other wavefronts: no barrier and no
+// cross-wave sums inside the loop, and a wavefront that waits for its samples does not hold up the other three.
 template <int DTYPE, int NTAP, int NIT>
 __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, const GcUnitSegs *__restrict__ gs,
                                         const GcRound *__restrict__ myrounds, int *__restrict__ pout, int ntap_stride,
@@ -196,18 +205,17 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     if (nround > rpw) nround = rpw;
 
     constexpr int LUTPOS = L::LUTPOS;
+    const int wv = tid >> 6, lane = tid & 63;
     uint2 *lut = reinterpret_cast<uint2 *>(smem);
-    int *wpre = reinterpret_cast<int *>(smem + L::WT_OFF);            // [2][8][2]: sums of the waves in front
-    int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF);         // [256 + 1]
-    int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF);          // [256 lanes][LPAD] + closing entry
-    int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x 2*NTAP
+    int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF + wv * L::LB_WAVE);       // [64 + 1]: sums in front of the lanes' spans, total
+    int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF + wv * L::LOC_WAVE);       // [64 lanes][LPAD] + closing entry
+    int *red = reinterpret_cast<int *>(smem + L::RED_OFF);            // 4 x (2*NTAP + 2)
     int *sk0 = reinterpret_cast<int *>(smem + L::K0_OFF);             // [ncar] + INT_MAX
     GcCarSeg *scar = reinterpret_cast<GcCarSeg *>(smem + L::CAR_OFF);
     GcCodeSeg *scode = reinterpret_cast<GcCodeSeg *>(smem + L::CODE_OFF);
 
     const gc_gptr_i8 ring = (gc_gptr_i8)c.ring;
     const uint64_t ringbytes = c.ringlen * (uint64_t)DTYPE;
-    const int wv = tid >> 6, lane = tid & 63;
     // A round whose 16-byte groups do not run over the end of the ring (all but one per ring
     // revolution) is loaded from a wave-uniform base plus the lane's offset, groups past the period's
     // end included: they stay inside the ring and are blanked below.
@@ -218,13 +226,13 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             const gc_gptr_i8 base = ring + rb;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const gc_u4v t4 = *(gc_gptr_u4)(base + (unsigned)(tid * NIT + it) * 16u);
+                const gc_u4v t4 = *(gc_gptr_u4)(base + (unsigned)(lane * NIT + it) * 16u);
                 dst[it] = make_uint4(t4.x, t4.y, t4.z, t4.w);
             }
         } else {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int g = g0 + r * RGRP + tid * NIT + it;
+                const int g = g0 + r * RGRP + lane * NIT + it;
                 uint64_t addr = u.a_al + (uint64_t)(g < G ? g : g0) * 16;
                 if (addr >= ringbytes) addr -= ringbytes;
                 const gc_u4v t4 = *(gc_gptr_u4)(ring + addr);
@@ -234,8 +242,12 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     };
     uint4 vA[NIT], vB[NIT];
     GC_PSTAMP(1);                                       // unit and channel constants are here
-    load_round(0, vA);                                  // in flight while the tables are set up
-    GcRound ronext = myrounds[0];                       // (likewise; every round asks for the next one's record)
+    GcRound ronext;
+    ronext.q0 = ronext.q1 = 0; ronext.clast = 0; ronext.w0 = 0; ronext.hint = 0;
+    if (wv < nround) {
+        load_round(wv, vA);                             // in flight while the tables are set up
+        ronext = myrounds[wv];                          // (likewise; every round asks for the next one's record)
+    }
 
     // ---- chip edges (ref src/sdrcmn.c:608-621 in closed form) --------------------------------
     // The replica position of chip M's first sample is B_M = min{j : T(j) >= M},
@@ -264,11 +276,10 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         }
         lut[tid] = v;
     }
-    // constant part of the prefix image: entry 0 of every lane (nothing summed yet) and of the closing lane
-    loc[tid * LPAD] = make_int2(0, 0);
-    if (tid == 0) { loc[256 * LPAD] = make_int2(0, 0); lbase[256] = make_int2(0, 0); }   // there P = slot 4 = total
-    for (int x = tid; x < 4 * 2 * NTAP; x += 256) red[x] = 0;        // waves without a chip edge skip the reduction
-    if (tid < 32) wpre[tid] = 0;
+    // constant part of the wavefront's prefix image: entry 0 of every lane (nothing summed yet) and of the closing lane
+    loc[lane * LPAD] = make_int2(0, 0);
+    if (lane == 0) loc[GC_PS_WLANES * LPAD] = make_int2(0, 0);       // there P = lbase[64] = the round's total
+    for (int x = tid; x < 4 * (2 * NTAP + 2); x += 256) red[x] = 0;  // wavefronts without a round leave their slots at zero
     __syncthreads();
     GC_PSTAMP(2);                                       // tables staged
 
@@ -281,8 +292,8 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         accQ[t] = 0;
         toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
     }
-    int wseg = 0;                                       // wave-uniform: carrier piece of the wave's first sample
-    bool busy = false;                                  // wave-uniform: this wave owned an edge in some round
+    int wseg = 0;                                       // wave-uniform: carrier piece of the round's first sample
+    bool busy = false;                                  // wave-uniform: this wave ran a round
     // start sample of edge q: from the unit's edge table (trk_edges) when there is one, else searched here
     const bool have_etab = etab_u != nullptr && u.eq0 >= 0;
     auto edge_js = [&](int q, int ed, int w, int hint) -> int {
@@ -299,16 +310,23 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         *w = w0;
         return edges[q];
     };
+    // the wavefront's own order between its LDS writes and the reads of other lanes' entries (one wavefront's LDS
+    // operations execute in order; this keeps the compiler from moving them across)
+    auto wave_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
     auto round = [&](int r, uint4 *vdata, uint4 *vnext) {
         // opaque copy of the lane id: per-lane address arithmetic stays inside the round instead of being
         // hoisted out of the loop over rounds into registers that would then spill
-        int tl = tid;
+        int tl = lane;
         asm volatile("" : "+v"(tl));
-        if (r + 1 < nround) load_round(r + 1, vnext);
+        if (r + 4 < nround) load_round(r + 4, vnext);
         // (the round's record was asked for a round ago: nothing here waits for memory it has just requested)
         const GcRound ro = ronext;
-        if (r + 1 < nround) ronext = myrounds[r + 1];
+        if (r + 4 < nround) ronext = myrounds[r + 4];
         const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0, rhint = ro.hint;
         int q = rq0 + tl, ew = 0, ed = 0, jsraw = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
@@ -316,37 +334,28 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             ed = edge_load(q, rw0, &ew);
             if (have_etab) jsraw = (int)etab_u[q - u.eq0];
         }
-        busy = busy || (rq0 + wv * 64 < q1);
-        const int kl = klo + r * RSAMP;
+        busy = true;
+        const int kl = klo + r * RSAMP;                 // the round's first sample
 
         // ---- phase A: carrier mixing (ref src/sdrcmn.c:643-662) and running sums ------------
         int aI = 0, aQ = 0, js = 0;
         const int roff = r * RSAMP;
-        const int kw = kl + wv * 64 * LSP;
-        // only the wavefronts that hold the period's first or last sample see samples outside [0, n) (one in
-        // the first round, one or two in the last): the others skip the blanking test altogether
-        const bool ragged = !(ablate & 4) && (kw < 0 || kw + 64 * LSP > n || g0 + r * RGRP + (wv + 1) * 64 * NIT > G);
-        // carrier pieces: the wave's 64 * LSP samples start in piece wseg; when no other piece starts
+        // only the rounds that hold the period's first or last sample see samples outside [0, n): the others skip
+        // the blanking test altogether
+        const bool ragged = !(ablate & 4) && (kl < 0 || kl + RSAMP > n || g0 + (r + 1) * RGRP > G);
+        // carrier pieces: the round's samples start in piece wseg; when no other piece starts
         // inside them (the common case -- a piece is a whole binade of the running phase) every lane
         // steps the same piece, otherwise each lane finds its own and switches where the next one starts
         // (every scan over the piece starts is bounded by the piece count: it never depends on the closing
         // sentinel alone -- an LDS read past the table returns 0 and would keep an unbounded scan going for ever)
-#ifdef GC_UNBOUNDED_SCANS       // (tools/debug: the round-2 form, kept to reproduce its stall)
-        while (sk0[wseg + 1] <= kw) wseg++;
-#else
-        while (wseg + 1 < ncar && sk0[wseg + 1] <= kw) wseg++;
-#endif
-        const bool onepiece = (ablate & 8) || wseg + 1 >= ncar || sk0[wseg + 1] >= kw + 64 * LSP;
+        while (wseg + 1 < ncar && sk0[wseg + 1] <= kl) wseg++;
+        const bool onepiece = (ablate & 8) || wseg + 1 >= ncar || sk0[wseg + 1] >= kl + RSAMP;
         auto run = [&](auto multi_tag) {
             constexpr bool MULTI = decltype(multi_tag)::value;
             int sp = wseg, knext = 0x7fffffff;
             const int kb0 = kl + tl * LSP;
             if (MULTI) {
-#ifdef GC_UNBOUNDED_SCANS
-                while (sk0[sp + 1] <= kb0) sp++;
-#else
                 while (sp + 1 < ncar && sk0[sp + 1] <= kb0) sp++;
-#endif
                 knext = sp + 1 < ncar ? sk0[sp + 1] : 0x7fffffff;
             }
             unsigned long long dfx = scar[sp].dfx;
@@ -402,34 +411,21 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                 }
             }
         };
-        if (r == 0) GC_PSTAMP(3);                       // round 0: edge record + piece scan done, samples needed now
+        if (r == wv) GC_PSTAMP(3);                      // first round: edge record + piece scan done, samples needed now
         if (!(ablate & 2)) { if (onepiece) run(std::false_type{}); else run(std::true_type{}); }
-        if (r == 0) GC_PSTAMP(4);                       // round 0: mixing done
+        if (r == wv) GC_PSTAMP(4);                      // first round: mixing done
         // the start sample of this lane's chip edge (no LDS involved: overlaps the image writes)
         if (q < q1) js = (have_etab ? jsraw : edge_js(q, ed, ew, rhint)) - roff;
         const int sI = wave_scan(aI), sQ = wave_scan(aQ);
-        // lanes 60..63 add this wave's total into the "waves in front" sums of the later waves and
-        // the grand total (slot 4): one LDS atomic per rail instead of a pass over all totals
-        int *wp = wpre + (r & 1) * 16;
+        lbase[tl] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span
+        if (tl == 63) lbase[GC_PS_WLANES] = make_int2(sI, sQ);      // the round's total, where the closing lane looks it up
         {
-            const int tI = __builtin_amdgcn_readlane(sI, 63), tQ = __builtin_amdgcn_readlane(sQ, 63);
-            const int slot = wv + 1 + (lane - 60);
-            if (lane >= 60 && slot <= 4) {
-                atomicAdd(&wp[2 * slot], tI);
-                atomicAdd(&wp[2 * slot + 1], tQ);
-            }
-        }
-        lbase[tl] = make_int2(sI - aI, sQ - aQ);       // sum in front of this lane's span inside its wave
-        if (r == 0) GC_PSTAMP(5);                       // round 0: scan + atomics
-        __syncthreads();
-        if (r == 0) GC_PSTAMP(6);                       // round 0: barrier
-        {
-            const int2 tv = *reinterpret_cast<const int2 *>(&wp[8]);
-            const int ti = __builtin_amdgcn_readfirstlane(tv.x), tq = __builtin_amdgcn_readfirstlane(tv.y);
+            const int ti = __builtin_amdgcn_readlane(sI, 63), tq = __builtin_amdgcn_readlane(sQ, 63);
             finI += (unsigned)rlast * (unsigned)ti;         // c_b P(S), the term of the round's last chip
             finQ += (unsigned)rlast * (unsigned)tq;
-            if (tl < 16) wpre[((r + 1) & 1) * 16 + tl] = 0;   // the other copy, for the next round
         }
+        wave_fence();
+        if (r == wv) GC_PSTAMP(5);                      // first round: scan
 
         // ---- phase B: one prefix look-up per chip edge and tap -------------------------------
         // (taps past ntap repeat tap 0 and are never written out; the +-1 code variant adds or
@@ -447,10 +443,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                     int ee = js - toff[t];
                     ee = ee < 0 ? 0 : (ee > RSAMP ? RSAMP : ee);
                     const int col = ee / LSP;             // the lane that owns sample ee; its image entry is ee + col
-                    // running sum inside the lane + lanes in front inside the wave + waves in front
+                    // running sum inside the lane + lanes in front
                     const int2 a = loc[ee + col], b = lbase[col];
-                    const int2 w = *reinterpret_cast<const int2 *>(&wp[2 * (col >> 6)]);
-                    const unsigned pI = (unsigned)(a.x + b.x + w.x), pQ = (unsigned)(a.y + b.y + w.y);
+                    const unsigned pI = (unsigned)(a.x + b.x), pQ = (unsigned)(a.y + b.y);
                     if (PM1) {
                         accI[t] += (pI ^ sg) - sg;
                         accQ[t] += (pQ ^ sg) - sg;
@@ -463,43 +458,47 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                         accQ[t] += mQ;
                     }
                 }
-                q += 256;
+                q += GC_PS_WLANES;
                 if (q < q1) { ed = edge_load(q, rw0, &ew); js = edge_js(q, ed, ew, rhint) - roff; }
             }
         };
         if (pm1) lookups(std::true_type{}); else lookups(std::false_type{});
-        if (r == 0) GC_PSTAMP(7);                       // round 0: look-ups
-        if (r + 1 < nround) __syncthreads();            // look-ups done before the image is rewritten
-        if (r == 0) GC_PSTAMP(8);                       // round 0: barrier
+        wave_fence();                                   // look-ups done before the wavefront rewrites its image
+        if (r == wv) GC_PSTAMP(7);                      // first round: look-ups
     };
-    for (int r = 0; r < nround; r += 2) {
+    for (int r = wv; r < nround; r += 8) {
         round(r, vA, vB);
-        if (r + 1 < nround) round(r + 1, vB, vA);
+        if (r + 4 < nround) round(r + 4, vB, vA);
     }
 
     GC_PSTAMP(9);                                       // all rounds
-    // wavefront then workgroup reduction (waves without an edge leave red[] at its initial zero)
+    // wavefront then workgroup reduction (wavefronts without a round leave red[] at its initial zero)
     if (busy) {
+        int *rw = red + wv * (2 * NTAP + 2);
 #pragma unroll
         for (int t = 0; t < NTAP; t++) {
             const int si = wave_sum63((int)accI[t]), sq = wave_sum63((int)accQ[t]);
             if (lane == 63) {
-                red[wv * 2 * NTAP + t] = si;
-                red[wv * 2 * NTAP + NTAP + t] = sq;
+                rw[t] = si;
+                rw[NTAP + t] = sq;
             }
         }
+        if (lane == 63) { rw[2 * NTAP] = (int)finI; rw[2 * NTAP + 1] = (int)finQ; }
     }
     __syncthreads();
     if (tid < ntap) {
-        unsigned si = 0, sq = 0;
+        unsigned si = 0, sq = 0, fI = 0, fQ = 0;
 #pragma unroll
         for (int w4 = 0; w4 < 4; w4++) {
-            si += (unsigned)red[w4 * 2 * NTAP + tid];
-            sq += (unsigned)red[w4 * 2 * NTAP + NTAP + tid];
+            const int *rw = red + w4 * (2 * NTAP + 2);
+            si += (unsigned)rw[tid];
+            sq += (unsigned)rw[NTAP + tid];
+            fI += (unsigned)rw[2 * NTAP];
+            fQ += (unsigned)rw[2 * NTAP + 1];
         }
         if (pm1) { si *= 2u; sq *= 2u; }
-        pout[tid] = (int)(si + finI);
-        pout[ntap_stride + tid] = (int)(sq + finQ);
+        pout[tid] = (int)(si + fI);
+        pout[ntap_stride + tid] = (int)(sq + fQ);
     }
     GC_PSTAMP(10);                                      // reduced and stored
 }

@@ -183,11 +183,12 @@ __global__ __launch_bounds__(GC_EXP_LANES) void trk_expand_kernel(const GcChan *
         return;
     }
 
-    // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel): round r of workgroup
+    // rounds of the prefix-sum correlator (same geometry as trk_corr_ps_kernel; a round is one wavefront's share,
+    // gnsscorr_ps.h): round r of workgroup
     // seg covers samples [kl, kl + rsamp) of the period and can touch the chips T(first sample) ..
     // T(last sample + 2 smax); rank[] turns those into positions in the code's edge list
     if (!rounds) { unit[i] = u; return; }
-    const int nitc = trk_ps_nit(c.dtype, nit), rgrp = 256 * nitc, rsamp = rgrp * (16 / c.dtype);
+    const int nitc = trk_ps_nit(c.dtype, nit), rgrp = GC_PS_WLANES * nitc, rsamp = rgrp * (16 / c.dtype);
     const int rpw = trk_ps_rounds(c.dtype, max_n, nitc);
     const unsigned short *rank = (const unsigned short *)(c.code + 1024);
     int eq0 = 0x7fffffff, eq1 = -1;
@@ -739,8 +740,11 @@ int gc_trk_nseg(int dtype, int max_n)
     const int groups = (15 + max_n * dtype + 15) / 16 + 1;
     // real (1-byte) samples carry 16 running sums per group: one group per lane keeps the LDS image small
     const int nit = g_trk_algo == 1 ? trk_ps_nit(dtype, g_trk_nit) : g_trk_nit;
-    const int rounds = (groups + 256 * nit - 1) / (256 * nit);
-    return g_trk_algo == 1 ? (rounds + GC_MAXR - 1) / GC_MAXR : rounds;
+    if (g_trk_algo == 1) {          // prefix-sum form: rounds of one wavefront each, GC_MAXR per workgroup
+        const int rounds = (groups + GC_PS_WLANES * nit - 1) / (GC_PS_WLANES * nit);
+        return (rounds + GC_MAXR - 1) / GC_MAXR;
+    }
+    return (groups + 256 * nit - 1) / (256 * nit);
 }
 
 int gc_launch_trk_expand(hipStream_t st, const GcChan *chan, const GcTrkPlan *plan, GcTrkUnit *unit, GcUnitSegs *segs,
