@@ -368,16 +368,18 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
                 if (ragged) {
                     const bool edge = kb < 0 || kb + SPG > n || g >= G;
                     if (__ballot(edge) != 0ULL) {
-                        if (edge) {                     // blank the samples outside [0, n)
+                        if (edge) {                     // blank the samples outside [0, n): the group's valid bytes are [blo, bhi)
+                            const int blo = kb < 0 ? -kb * DTYPE : 0;
+                            int bhi = (n - kb) * DTYPE;
+                            bhi = (g >= G || bhi < 0) ? 0 : (bhi > 16 ? 16 : bhi);
                             unsigned m[4];
 #pragma unroll
                             for (int d = 0; d < 4; d++) {
-                                m[d] = 0;
-#pragma unroll
-                                for (int b = 0; b < 4; b++) {
-                                    const int k = kb + (d * 4 + b) / DTYPE;
-                                    if (k >= 0 && k < n && g < G) m[d] |= 0xFFu << (8 * b);
-                                }
+                                int lo = blo - 4 * d, hi = bhi - 4 * d;
+                                lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+                                hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+                                // (hi > lo: 1 <= hi <= 4 and lo <= 3, both shifts stay below 32)
+                                m[d] = hi > lo ? ((0xFFFFFFFFu >> (8 * (4 - hi))) & (0xFFFFFFFFu << (8 * lo))) : 0u;
                             }
                             v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
                         }
