@@ -191,6 +191,17 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     if (tid == 0 && (blockIdx.x % 15) == 0 && blockIdx.x / 15 < GC_PS_TRACE_N) ptr_ = gc_ps_trace + (blockIdx.x / 15) * 16;
     GC_PSTAMP(0);
 #endif
+    // this thread's element of the unit's NCO tables, requested before anything waits for the unit's record (the piece
+    // counts are in it: elements past them are stale and never copied to LDS) -- the two round trips overlap
+    int k0r = 0;
+    GcCarSeg carr;
+    GcCodeSeg coder;
+    carr.fx = carr.dfx = 0;
+    coder.y0 = coder.d = coder.inv = coder.ylast = 0.0; coder.j0 = coder.cnt = coder.w = coder.pad = 0;
+    if (gs) {
+        if (tid < GC_NCAR) { k0r = gs->carK0[tid]; carr = gs->car[tid]; }
+        else if (tid >= 64 && tid - 64 < GC_NCODE) coder = gs->code[tid - 64];
+    }
     const int ntap = c.ntap;
     const int n = u.n, smax = c.smax, head = u.head, G = u.G;
     const int g0 = seg * RGRP * rpw;
@@ -205,7 +216,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     if (nround > rpw) nround = rpw;
 
     constexpr int LUTPOS = L::LUTPOS;
-    const int wv = tid >> 6, lane = tid & 63;
+    // (the wavefront number as a scalar: everything derived from it -- round index, sample window, table scans -- stays
+    // on the scalar unit instead of being computed per lane under execution masks)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     uint2 *lut = reinterpret_cast<uint2 *>(smem);
     int2 *lbase = reinterpret_cast<int2 *>(smem + L::LB_OFF + wv * L::LB_WAVE);       // [64 + 1]: sums in front of the lanes' spans, total
     int2 *loc = reinterpret_cast<int2 *>(smem + L::LOC_OFF + wv * L::LOC_WAVE);       // [64 lanes][LPAD] + closing entry
@@ -259,9 +272,9 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     const int nedge = c.nedge;
     const int ncar = u.ncar, ncode = u.ncode;
     if (gs) {
-        if (tid < ncar) { sk0[tid] = gs->carK0[tid]; scar[tid] = gs->car[tid]; }
+        if (tid < ncar) { sk0[tid] = k0r; scar[tid] = carr; }
         if (tid == ncar) sk0[tid] = 0x7fffffff;
-        if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = gs->code[tid - 64];
+        if (tid >= 64 && tid - 64 < ncode) scode[tid - 64] = coder;
     }
     if (tid < 32 * LUTPOS) {
         const int idx = tid & 31, pos = tid >> 5;
@@ -296,6 +309,10 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     bool busy = false;                                  // wave-uniform: this wave ran a round
     // start sample of edge q: from the unit's edge table (trk_edges) when there is one, else searched here
     const bool have_etab = etab_u != nullptr && u.eq0 >= 0;
+    // (a readable address in either case: the entry is requested unconditionally, see the rounds)
+    const unsigned short __attribute__((address_space(1))) *etab_any =
+        have_etab ? (const unsigned short __attribute__((address_space(1))) *)etab_u
+                  : (const unsigned short __attribute__((address_space(1))) *)c.code;
     auto edge_js = [&](int q, int ed, int w, int hint) -> int {
         if (have_etab) return (int)etab_u[q - u.eq0];
         return gc_edge_start(scode, ncode, ed, w, hint);
@@ -308,7 +325,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             w0 += wq;
         }
         *w = w0;
-        return edges[q];
+        return edges[q < nedge ? q : nedge - 1];        // (q < nedge for every edge of a round; the clamp serves lanes without one)
     };
     // the wavefront's own order between its LDS writes and the reads of other lanes' entries (one wavefront's LDS
     // operations execute in order; this keeps the compiler from moving them across)
@@ -323,17 +340,27 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // hoisted out of the loop over rounds into registers that would then spill
         int tl = lane;
         asm volatile("" : "+v"(tl));
-        if (r + 4 < nround) load_round(r + 4, vnext);
         // (the round's record was asked for a round ago: nothing here waits for memory it has just requested)
         const GcRound ro = ronext;
-        if (r + 4 < nround) ronext = myrounds[r + 4];
+        // Every pass issues the SAME vector-memory loads in the same order -- this lane's edge entry and its start
+        // sample (index clamped into the range where the lane has no edge), then the samples of the wavefront's next
+        // round (its last round asks for its own again) -- with no branch around any of them: the memory counter is
+        // in-order, and only then can the compiler wait for exactly the loads that are older than the ones it still
+        // wants in flight during the mixing phase (with a skipped load on any path it waits for all of them, the
+        // samples just requested included).
+        const int rn = r + 4 < nround ? r + 4 : r;
+        ronext = myrounds[rn];
         const int rq0 = ro.q0, rq1 = ro.q1, rlast = ro.clast, rw0 = ro.w0, rhint = ro.hint;
         int q = rq0 + tl, ew = 0, ed = 0, jsraw = 0;
         const int q1 = (ablate & 1) ? 0 : rq1;
-        if (q < q1) {                                   // in flight during the mixing phase
-            ed = edge_load(q, rw0, &ew);
-            if (have_etab) jsraw = (int)etab_u[q - u.eq0];
+        {
+            const int qc = q < q1 ? q : rq0;
+            ed = edge_load(qc, rw0, &ew);
+            int xe = have_etab ? qc - u.eq0 : 0;
+            xe = xe < 0 ? 0 : (xe > GC_EDGTAB - 1 ? GC_EDGTAB - 1 : xe);
+            jsraw = (int)etab_any[xe];
         }
+        load_round(rn, vnext);
         busy = true;
         const int kl = klo + r * RSAMP;                 // the round's first sample
 
@@ -363,7 +390,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int gl = tl * NIT + it, g = g0 + r * RGRP + gl;
-                uint4 v = vdata[it];
+                uint4 &v = vdata[it];               // (blanked in place: the register set is dead after this round)
                 const int kb = kl + gl * SPG;
                 if (ragged) {
                     const bool edge = kb < 0 || kb + SPG > n || g >= G;
