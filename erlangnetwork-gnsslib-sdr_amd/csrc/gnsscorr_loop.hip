@@ -14,8 +14,8 @@
 //                  (partial sums -> II/QQ, sdrnavigation's bit sync / bit decision, cumsumcorr, pll/dll where due,
 //                  log rows) and plans the next one (the exact NCO chain of gnsscorr_nco.h with the piece tables of
 //                  every period, unit constants and rounds, written for the correlator).
-//   trk_step_corr  (channel, period of the interval, round) -> one 256-lane workgroup running ps_unit
-//                  (gnsscorr_ps.h) on one round of 4096 IQ samples; int32 partial sums per workgroup.
+//   trk_step_corr  (channel, period of the interval, quarter) -> one 256-lane workgroup running ps_unit
+//                  (gnsscorr_ps.h) on four rounds of 1024 IQ samples, one per wavefront; int32 partial sums per workgroup.
 //
 // Round 2 ran all of this in ONE workgroup per channel, period by period (32 of 256 CUs busy, 35 us per period).
 #include <cstdlib>

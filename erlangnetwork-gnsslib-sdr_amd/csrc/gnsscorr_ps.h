@@ -70,15 +70,17 @@ __device__ __forceinline__ int wave_sum63(int v)
 // running sums.
 //
 // One workgroup serves one (channel, epoch) [or a long period's share of it]
-// in rounds of 256*NIT sample groups that reuse one LDS image:
+// in rounds of 64*NIT sample groups; a round is ONE WAVEFRONT's work, on the
+// wavefront's own LDS image, and the workgroup's wavefronts take the rounds in turn:
 //   phase A  lane L mixes its NIT consecutive groups (two chained dot4 per
-//            sample) and stores the running sums loc[p][L] (p samples into
-//            the lane's span; row 0 is constant zero); a DPP scan over the
-//            wavefront and the per-wave totals turn the lane totals into
-//            lbase[L], the sum in front of the lane's span.
-//   phase B  one chip edge per thread: B_m from the closed-form code NCO (a
-//            reciprocal estimate, corrected against T itself), then per tap
-//            P = loc + lbase at the clamped sample position.
+//            sample) and stores the running sums loc[L][p] (p samples into
+//            the lane's span; entry 0 is constant zero); a DPP scan over the
+//            wavefront turns the lane totals into lbase[L], the sum in front
+//            of the lane's span, and the round's total.
+//   phase B  one chip edge per lane: B_m from the unit's edge table, or from
+//            the code piece that holds it (a reciprocal estimate, corrected
+//            against T itself), then per tap P = loc + lbase at the clamped
+//            sample position.
 // Accumulators stay in registers over the rounds; one reduction at the end.
 // cost[i] of the carrier LUT from immediates (no table load on the workgroup's critical path):
 // eight dwords of four int8 entries each
