@@ -397,17 +397,19 @@ def test_planner_chain_wide_correlator_spacing(gc, orc, engine):
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
 
 
-def test_trk_20msps_period(gc, orc, engine):
-    """A 20 Msps front end (ref frontend/stereo_L1G1.ini): 20000 samples per code period, five rounds of the
-    correlator per period."""
-    f_sf = 20e6
-    nsamples = 20000 * 8
+@pytest.mark.parametrize("f_sf,dtype", [(20e6, 2), (26e6, 2), (26e6, 1)])
+def test_trk_20msps_period(gc, orc, engine, f_sf, dtype):
+    """A 20 Msps front end (ref frontend/stereo_L1G1.ini): 20000 samples per code period, twenty rounds of the
+    correlator (one wavefront each) per period; at 26 Msps the period's 26 rounds no longer fit one workgroup
+    (GC_MAXR) and two workgroups share it, for IQ and for real samples."""
+    nper = int(f_sf * 1e-3)
+    nsamples = nper * 8
     rng = np.random.default_rng(2000)
-    data = rng.integers(-100, 101, size=(nsamples, 2), dtype=np.int8)
-    engine.ring_create(1, 2, nsamples)
+    data = rng.integers(-100, 101, size=(nsamples, 2) if dtype == 2 else (nsamples,), dtype=np.int8)
+    engine.ring_create(1, dtype, nsamples)
     engine.ring_push_raw(1, data, nsamples)
-    chans = [gc.Channel(p, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for p in (7, 24)]
-    assert chans[0].nsamp == 20000
+    chans = [gc.Channel(p, dtype=dtype, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for p in (7, 24)]
+    assert chans[0].nsamp == nper
     engine.set_channels(chans)
     states = [dict(carrfreq=float(rng.uniform(-3000, 3000)), codefreq=c.crate + float(rng.uniform(-1, 1)),
                    remcode=float(rng.uniform(0.1, 0.9)), remcarr=float(rng.uniform(0, 6)), buffloc=11 + 300 * i)
@@ -415,9 +417,9 @@ def test_trk_20msps_period(gc, orc, engine):
     engine.trk_set_state(states)
     engine.trk_run(5)
     II, QQ, ns = engine.trk_fetch()
-    ochs = [orc.make_chan(c.prn, dtype=2, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for c in chans]
+    ochs = [orc.make_chan(c.prn, dtype=dtype, f_sf=f_sf, f_if=0.0, corrn=2, corrd=4, corrp=4) for c in chans]
     oII, oQQ, ons, ofin = _oracle_run(orc, ochs, states, data, nsamples, nsamples, 5)
-    assert np.array_equal(ns, ons) and ns[:, 1:].min() >= 19999      # (the first period is cut by remcode)
+    assert np.array_equal(ns, ons) and ns[:, 1:].min() >= nper - 1      # (the first period is cut by remcode)
     assert np.array_equal(II, oII) and np.array_equal(QQ, oQQ)
     # (acquisition of such a stream: tests/test_gpu_acq.py::test_acquisition_long_periods_65536_point_transform)
 
