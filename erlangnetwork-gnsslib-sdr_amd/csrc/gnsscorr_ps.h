@@ -204,7 +204,13 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         if (tid < GC_NCAR) { k0r = gs->carK0[tid]; carr = gs->car[tid]; }
         else if (tid >= 64 && tid - 64 < GC_NCODE) coder = gs->code[tid - 64];
     }
+    // the channel's constants, all requested here: a field first read behind the barrier below would cost the workgroup
+    // one more round trip to memory after it (the compiler does not move loads across a barrier)
     const int ntap = c.ntap;
+    const int pm1_raw = c.pm1;
+    int tapv[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) tapv[t] = c.tapoff[t < GNSSCORR_MAXTAPS ? t : 0];
     const int n = u.n, smax = c.smax, head = u.head, G = u.G;
     const int g0 = seg * RGRP * rpw;
     // nothing to correlate (trk_expand: outside the reference's scratch, undefined chip step, NCO table
@@ -295,17 +301,21 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
     loc[lane * LPAD] = make_int2(0, 0);
     if (lane == 0) loc[GC_PS_WLANES * LPAD] = make_int2(0, 0);       // there P = lbase[64] = the round's total
     for (int x = tid; x < 4 * (2 * NTAP + 2); x += 256) red[x] = 0;  // wavefronts without a round leave their slots at zero
+    // (the constants requested at the top are here by now: pinned, so that their loads cannot sink behind the barrier)
+    asm volatile("" :: "s"(pm1_raw));
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) asm volatile("" :: "s"(tapv[t]));
     __syncthreads();
     GC_PSTAMP(2);                                       // tables staged
 
-    const bool pm1 = c.pm1 != 0;
+    const bool pm1 = pm1_raw != 0;
     unsigned accI[NTAP], accQ[NTAP], finI = 0, finQ = 0;
     int toff[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; t++) {
         accI[t] = 0;
         accQ[t] = 0;
-        toff[t] = smax + (t < ntap ? c.tapoff[t] : 0) + klo;
+        toff[t] = smax + (t < ntap ? tapv[t] : 0) + klo;
     }
     int wseg = 0;                                       // wave-uniform: carrier piece of the round's first sample
     bool busy = false;                                  // wave-uniform: this wave ran a round
@@ -342,6 +352,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // hoisted out of the loop over rounds into registers that would then spill
         int tl = lane;
         asm volatile("" : "+v"(tl));
+        if (r == wv) GC_PSTAMP(11);                     // first round entered
         // (the round's record was asked for a round ago: nothing here waits for memory it has just requested)
         const GcRound ro = ronext;
         // Every pass issues the SAME vector-memory loads in the same order -- this lane's edge entry and its start
@@ -363,6 +374,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
             jsraw = (int)etab_any[xe];
         }
         load_round(rn, vnext);
+        if (r == wv) GC_PSTAMP(12);                     // first round: loads issued
         busy = true;
         const int kl = klo + r * RSAMP;                 // the round's first sample
 
@@ -379,6 +391,7 @@ __device__ __forceinline__ void ps_unit(const GcChan &c, const GcTrkUnit &u, con
         // sentinel alone -- an LDS read past the table returns 0 and would keep an unbounded scan going for ever)
         while (wseg + 1 < ncar && sk0[wseg + 1] <= kl) wseg++;
         const bool onepiece = (ablate & 8) || wseg + 1 >= ncar || sk0[wseg + 1] >= kl + RSAMP;
+        if (r == wv) GC_PSTAMP(13);                     // first round: piece scan done
         auto run = [&](auto multi_tag) {
             constexpr bool MULTI = decltype(multi_tag)::value;
             int sp = wseg, knext = 0x7fffffff;

@@ -26,10 +26,14 @@ t = np.zeros(2048 * 16, dtype=np.uint64)
 gc.lib().gnsscorr_debug_ps_trace(C.c_void_p(t.ctypes.data))
 x = t.reshape(2048, 16).astype(np.int64)
 x = x[(x[:, 10] > x[:, 0]) & (x[:, 0] > 0)]
-names = ["unit + channel constants", "tables staged (+barrier)", "round 0: records, piece scan", "round 0: mixing (waits for the samples)",
-         "round 0: scan + atomics", "round 0: barrier", "round 0: look-ups", "round 0: barrier", "rounds 1..3", "reduce + store"]
+# stamps of wavefront 0 (gnsscorr_ps.h): 0 entry, 1 constants, 2 tables staged, 11 first round entered, 12 its loads issued,
+# 13 piece scan done, 3 mixing starts, 4 mixed,
+# 5 scanned, 7 looked up, 9 all its rounds done, 10 reduced and stored
+idx = [0, 1, 2, 11, 12, 13, 3, 4, 5, 7, 9, 10]
+names = ["unit + channel constants", "tables staged (+barrier)", "accumulators, tap offsets", "first round: record, loads issued", "first round: piece scan", "first round: lane phase", "first round: mixing",
+         "first round: scan", "first round: look-ups", "the wavefront's other rounds", "barrier + reduce + store"]
 print("sampled workgroups", len(x), " lifetime clocks mean %.0f median %.0f" % ((x[:, 10] - x[:, 0]).mean(), np.median(x[:, 10] - x[:, 0])))
 for i, n in enumerate(names):
-    d = x[:, i + 1] - x[:, i]
-    print("  %-42s mean %7.0f median %7.0f p90 %7.0f" % (n, d.mean(), np.median(d), np.percentile(d, 90)))
+    d = x[:, idx[i + 1]] - x[:, idx[i]]
+    print("  %-46s mean %7.0f median %7.0f p90 %7.0f" % (n, d.mean(), np.median(d), np.percentile(d, 90)))
 PY
