@@ -2,11 +2,12 @@
 
 The default planner evaluates most periods from claims proved for a bracket around the period's start
 (gnsscorr_plan.hip); GNSSCORR_TRK_NOSPEC=1 selects the older chain that certifies every step itself, and
-GNSSCORR_PLAN_VERIFY=1 keeps the claims but runs every step with its checks.  The three must agree bit for bit on
-everything a batch returns.  This script runs one mode (argv[1]: default | nospec | verify) over a seeded family of
+GNSSCORR_PLAN_VERIFY=1 keeps the claims but runs every step with its checks; GNSSCORR_TRK_ALGO=replica swaps the
+prefix-sum correlator for the independent sample-by-sample form.  The four must agree bit for bit on everything a
+batch returns.  This script runs one mode (argv[1]: default | nospec | verify | replica) over a seeded family of
 configurations -- front ends (IQ at zero IF, real samples at 4.092 MHz IF), sampling rates, tap sets, Doppler up
 to +-10 kHz, code frequency offsets up to +-12 chips/s, starts close to 0 and to 1 chip, GLONASS channels -- and
-prints one digest line per configuration; `plan_sweep.py all` runs the three modes as child processes and compares
+prints one digest line per configuration; `plan_sweep.py all` runs the four modes as child processes and compares
 the lines."""
 import hashlib
 import json
@@ -46,7 +47,12 @@ def run_mode():
     import ctypes as C
     import gnsscorr_loader
     gc = gnsscorr_loader.load()
+    only = os.environ.get("SWEEP_ONLY")
     for ci, cfg in enumerate(configs()):
+        if only is not None and ci != int(only):
+            continue
+        if ci < int(os.environ.get("SWEEP_FROM", "0")) or ci > int(os.environ.get("SWEEP_TO", "1000000")):
+            continue
         eng = gc.Engine(0)
         fe, (corrn, corrd, corrp) = cfg["fe"], cfg["taps"]
         rng = np.random.default_rng(cfg["seed"])
@@ -74,9 +80,12 @@ def run_mode():
         stats = np.zeros(8, dtype=np.uint64)
         gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
         h = hashlib.sha256()
+        dump = []
         for b in range(NBATCH):
             eng.trk_run(NEPOCH)
             II, QQ, ns = eng.trk_fetch()
+            if os.environ.get("SWEEP_DUMP") and ci == int(os.environ.get("SWEEP_DUMPCFG", "-1")):
+                dump += [II.copy(), QQ.copy(), ns.copy()]
             h.update(np.ascontiguousarray(II).tobytes())
             h.update(np.ascontiguousarray(QQ).tobytes())
             h.update(np.ascontiguousarray(ns).tobytes())
@@ -86,6 +95,8 @@ def run_mode():
         gc.lib().gnsscorr_debug_plan_stats(C.c_void_p(stats.ctypes.data), 1)
         print(json.dumps(dict(cfg=ci, fe=fe, taps=cfg["taps"], nch=cfg["nch"], dopp=cfg["dopp"], dcode=cfg["dcode"],
                               digest=h.hexdigest(), stats=stats.tolist())), flush=True)
+        if dump:
+            np.savez(os.environ["SWEEP_DUMP"], *dump)
         eng.close()
 
 
@@ -95,7 +106,8 @@ def main():
         run_mode()
         return 0
     lines = {}
-    for m, env_add in (("default", {}), ("nospec", dict(GNSSCORR_TRK_NOSPEC="1")), ("verify", dict(GNSSCORR_PLAN_VERIFY="1"))):
+    for m, env_add in (("default", {}), ("nospec", dict(GNSSCORR_TRK_NOSPEC="1")), ("verify", dict(GNSSCORR_PLAN_VERIFY="1")),
+                       ("replica", dict(GNSSCORR_TRK_ALGO="replica"))):
         env = dict(os.environ, **env_add)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), m], env=env, capture_output=True, text=True, timeout=int(os.environ.get("SWEEP_TIMEOUT", "240")))
         if out.returncode != 0:
@@ -105,12 +117,12 @@ def main():
         print(m, len(lines[m]), "configurations", flush=True)
     bad = 0
     tot = np.zeros(8, dtype=np.int64)
-    for d, n, v in zip(lines["default"], lines["nospec"], lines["verify"]):
-        same = d["digest"] == n["digest"] == v["digest"]
+    for d, n, v, rp in zip(lines["default"], lines["nospec"], lines["verify"], lines["replica"]):
+        same = d["digest"] == n["digest"] == v["digest"] == rp["digest"]
         tot += np.array(d["stats"], dtype=np.int64)
         if not same or v["stats"][6] != 0:
             bad += 1
-            print("MISMATCH", d, n["digest"], v["digest"], v["stats"])
+            print("MISMATCH", d, n["digest"], v["digest"], rp["digest"], v["stats"])
     print("configurations", len(lines["default"]), "mismatches", bad, "planner paths (default mode, summed)", tot.tolist())
     return 1 if bad else 0
 
